@@ -1,0 +1,109 @@
+"""ctypes binding of libadaface_hip.so (include/adaface_hip.h).
+
+The library is the product: if it is missing or fails to load this module raises —
+there is no CPU or eager-PyTorch fallback anywhere in adaface_amd.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+AF_DTYPE_BF16 = 0
+AF_DTYPE_F32 = 1
+DTYPES = {"bf16": AF_DTYPE_BF16, "bfloat16": AF_DTYPE_BF16, "f32": AF_DTYPE_F32, "fp32": AF_DTYPE_F32,
+          "float32": AF_DTYPE_F32}
+
+_LIB_PATH = Path(__file__).resolve().parent / "libadaface_hip.so"
+
+
+class AfConfig(C.Structure):
+    """struct af_config (include/adaface_hip.h)."""
+    _fields_ = [
+        ("dtype", C.c_int),
+        ("build_unet", C.c_int),
+        ("in_channels", C.c_int), ("model_channels", C.c_int), ("out_channels", C.c_int),
+        ("num_res_blocks", C.c_int),
+        ("n_attention_resolutions", C.c_int), ("attention_resolutions", C.c_int * 8),
+        ("n_channel_mult", C.c_int), ("channel_mult", C.c_int * 8),
+        ("num_heads", C.c_int), ("context_dim", C.c_int), ("transformer_depth", C.c_int),
+        ("n_context_layers", C.c_int),
+        ("build_vae", C.c_int),
+        ("vae_ch", C.c_int), ("vae_out_ch", C.c_int), ("vae_num_res_blocks", C.c_int),
+        ("vae_z_channels", C.c_int), ("vae_embed_dim", C.c_int),
+        ("n_vae_ch_mult", C.c_int), ("vae_ch_mult", C.c_int * 8),
+    ]
+
+
+class AfError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/adaface_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_SIGS = [
+    ("af_last_error", C.c_char_p, []),
+    ("af_version", C.c_int, []),
+    ("af_create", C.c_int, [C.c_int, C.POINTER(AfConfig), C.POINTER(_P)]),
+    ("af_destroy", None, [_P]),
+    ("af_load_tensor", C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64)]),
+    ("af_num_tensors", C.c_int, [_P]),
+    ("af_tensor_name", C.c_char_p, [_P, C.c_int]),
+    ("af_tensor_loaded", C.c_int, [_P, C.c_int]),
+    ("af_tensor_shape", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
+    ("af_set_context", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    ("af_unet_forward", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    ("af_ddim_step", C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                               C.c_float, _P, _P, _P]),
+    ("af_vae_decode", C.c_int, [_P, _P, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    ("af_to_uint8", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    ("af_arena_bytes", C.c_int64, [_P]),
+    ("af_op_conv2d", C.c_int, [C.c_int, _P, _P, _P, _P, _P] + [C.c_int] * 9 + [_P]),
+    ("af_op_linear", C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
+    ("af_op_groupnorm", C.c_int, [C.c_int, _P, _P, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    ("af_op_layernorm", C.c_int, [C.c_int, _P, _P, _P, C.c_float, _P, C.c_int64, C.c_int, _P]),
+    ("af_op_attention", C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
+    ("af_op_timestep_embedding", C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P]),
+]
+EXPORTED_SYMBOLS = [s[0] for s in _SIGS]
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library (once) and declare every entry point's signature."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise AfError(
+            f"{_LIB_PATH} not found: build it with `python -m adaface_amd.build` (needs hipcc). "
+            "adaface_amd has no fallback path.")
+    lib = C.CDLL(os.fspath(_LIB_PATH))
+    for name, res, args in _SIGS:
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().af_last_error().decode("utf-8", "replace")
+        raise AfError(f"{what or 'libadaface_hip'} failed (rc={rc}): {msg}")
+
+
+def stream_ptr():
+    """Current torch HIP stream as a void* for the C ABI."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device/host data pointer of a tensor (None -> NULL)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())

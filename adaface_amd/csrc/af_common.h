@@ -1,0 +1,147 @@
+// adaface_amd — shared device/host definitions for the gfx950 (MI355X) kernels.
+//
+// Storage type T is either __bf16 (throughput mode) or float (parity mode).
+// All activations are NHWC ("token-major"): [B, H*W, C] with C contiguous, so
+// the reference's 'b c h w -> b (h w) c' rearranges (attention.py:327,335) are
+// no-ops and every 1x1 conv / Linear is a plain row-major GEMM.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define AF_WAVE 64
+
+#define HIP_CHECK_RET(expr)                                                       \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess) {                                                       \
+      af_set_error_msg("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),     \
+                       __FILE__, __LINE__);                                       \
+      return -2;                                                                  \
+    }                                                                             \
+  } while (0)
+
+void af_set_error_msg(const char* fmt, ...);
+
+// ---------------------------------------------------------------------------
+// scalar conversion helpers
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// 16-byte vector of storage elements (8 bf16 or 4 float)
+template <typename T> struct Vec16 {
+  static constexpr int N = 16 / sizeof(T);
+  union {
+    uint4 u;
+    T e[N];
+  };
+};
+
+// 4 consecutive storage elements (8 B for bf16, 16 B for float)
+template <typename T> struct Quad;
+template <> struct Quad<bf16> {
+  union {
+    uint2 u;
+    bf16 e[4];
+  };
+  __device__ __forceinline__ void load(const bf16* p) { u = *reinterpret_cast<const uint2*>(p); }
+  __device__ __forceinline__ void store(bf16* p) const { *reinterpret_cast<uint2*>(p) = u; }
+};
+template <> struct Quad<float> {
+  union {
+    uint4 u;
+    float e[4];
+  };
+  __device__ __forceinline__ void load(const float* p) { u = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<uint4*>(p) = u; }
+};
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// exact (erf) GELU, as F.gelu default (attention.py:41)
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// ---------------------------------------------------------------------------
+// MFMA wrapper: one "fragment step" consumes a 16-byte fragment per lane from
+// each operand (= 32 bytes of K per row: 16 bf16 or 8 float).
+//   bf16 : one v_mfma_f32_32x32x16_bf16      (lane l: row l&31, k = 8*(l>>5)+j)
+//   float: four v_mfma_f32_32x32x2_f32, MFMA j taking element j of the
+//          fragment, i.e. k = 4*(l>>5)+j : a fixed permutation of K applied
+//          identically to both operands, so the sum is unchanged.
+// D[i][j] = sum_k A[i][k]*B[k][j]; D col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5).
+// ---------------------------------------------------------------------------
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+  static __device__ __forceinline__ void step(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static __device__ __forceinline__ void step(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.x),
+                                             __builtin_bit_cast(float, b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.y),
+                                             __builtin_bit_cast(float, b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.z),
+                                             __builtin_bit_cast(float, b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.w),
+                                             __builtin_bit_cast(float, b.w), c, 0, 0, 0);
+  }
+};
+
+// row of the 32x32 accumulator held in register r of lane-half h
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---------------------------------------------------------------------------
+// kernel parameter blocks (plain structs passed by value)
+// ---------------------------------------------------------------------------
+enum { AF_EPI_NONE = 0, AF_EPI_GEGLU = 1 };
+
+// Implicit-GEMM convolution / linear:  out[m][n] = sum_k X(m,k) * W[n][k] (+epilogue)
+//   m = (b, oy, ox), k = (ky, kx, c).  ks==1 degenerates to a row-major GEMM.
+struct ConvGemmParams {
+  const void* src;        // activations, T, NHWC
+  long src_batch_stride;  // elements between samples
+  int ldc;                // elements between pixels (>= Cin)
+  int Cin;                // input channels used (multiple of BK)
+  int Hs, Ws;             // stored source spatial dims
+  int up;                 // 1: nearest-2x upsample folded into the gather
+  int Hi, Wi;             // logical input dims (Hs<<up, Ws<<up)
+  int Ho, Wo;             // output dims
+  int ks, stride, pad;
+  const void* W;          // T, [Wrows][ldw]
+  int ldw;                // elements between weight rows (>= K)
+  int Wrows;              // rows that may be read (padded rows are zero)
+  int M, N, K;            // N = valid GEMM columns (multiple of 4)
+  const float* bias;      // [N] or null
+  const void* rowbias;    // T, [B][ldrb] per-sample bias (time embedding) or null
+  int ldrb;
+  const void* residual;   // T, [M][ldr] or null
+  int ldr;
+  void* out;              // T, [M][ldo]
+  int ldo;
+  int epilogue;
+  float alpha;            // scale applied to the accumulator before bias
+  // batched GEMM (blockIdx.z): element strides
+  long bs_src, bs_w, bs_out, bs_res;
+};
+
+struct AttnParams {
+  const void* q; const void* k; const void* v; void* o;  // T
+  int ldq, ldk, ldv, ldo;        // row strides (elements)
+  long bsq, bsk, bsv, bso;       // batch strides (elements)
+  int Nq, Nk, H;
+  float scale;
+};

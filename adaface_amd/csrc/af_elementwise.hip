@@ -1,0 +1,339 @@
+// Small HBM-bound kernels around the contractions: layout conversion at the C-ABI
+// boundary (the reference speaks NCHW fp32, the kernels NHWC T), timestep embedding
+// (ldm/modules/diffusionmodules/util.py:154-174), the fused CFG + DDIM update
+// (ldm/models/diffusion/ddim.py:260,273-295), row softmax for the VAE's single-head
+// attention (ldm/modules/diffusionmodules/model.py:222-236), channel concat
+// (openaimodel.py:1019) and the image post-process (scripts/stable_txt2img.py:715,764-765).
+#include "af_common.h"
+#include <math.h>
+
+#define EW_GRID(n) dim3((unsigned)(((n) + 255) / 256 > 65535 * 16 ? 65535 * 16 : ((n) + 255) / 256))
+
+// NCHW fp32 [B,C,H,W] -> NHWC T [B,H*W,Cpad] (channels >= C zero), scaled
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int Cn, int HW,
+                                    int Cpad, float scale) {
+  const long n = (long)B * HW * Cpad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cpad);
+    const long bp = i / Cpad;
+    const int pix = (int)(bp % HW);
+    const long b = bp / HW;
+    float v = 0.f;
+    if (c < Cn) v = x[(b * Cn + c) * HW + pix] * scale;
+    y[i] = from_f32<T>(v);
+  }
+}
+
+// NHWC T [B,HW,ld] (first C channels) -> NCHW fp32 [B,C,H,W]
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int B, int Cn, int HW,
+                                    int ld) {
+  const long n = (long)B * Cn * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int pix = (int)(i % HW);
+    const long bc = i / HW;
+    const int c = (int)(bc % Cn);
+    const long b = bc / Cn;
+    y[i] = to_f32<T>(x[(b * HW + pix) * ld + c]);
+  }
+}
+
+// fp32 -> T cast, contiguous
+template <typename T>
+__global__ void cast_f32_kernel(const float* __restrict__ x, T* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = from_f32<T>(x[i]);
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ x, float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = to_f32<T>(x[i]);
+}
+
+// timestep_embedding: emb[b] = [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(max_period)*i/half)
+// (util.py:163-169; cosine half FIRST).  Output T [B, dim].
+template <typename T>
+__global__ void timestep_embedding_kernel(const long long* __restrict__ t, T* __restrict__ y, int B, int dim) {
+  const int half = dim / 2;
+  const int n = B * dim;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int b = i / dim, j = i % dim;
+    float v = 0.f;
+    if (j < 2 * half) {
+      const int k = j < half ? j : j - half;
+      const float freq = expf(-9.210340371976184f * (float)k / (float)half);
+      const float arg = (float)t[b] * freq;
+      v = j < half ? cosf(arg) : sinf(arg);
+    }
+    y[i] = from_f32<T>(v);
+  }
+}
+
+// y = silu(x) elementwise (T)
+template <typename T>
+__global__ void silu_kernel(const T* __restrict__ x, T* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float f = to_f32<T>(x[i]);
+    y[i] = from_f32<T>(f / (1.0f + expf(-f)));
+  }
+}
+
+// dst[pix][off + c] = src[pix][c]   (channel concat; 16-byte vectors)
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd, int off,
+                                     int Cn, long npix) {
+  constexpr int EPC = 16 / sizeof(T);
+  const int NV = Cn / EPC;
+  const long n = npix * NV;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / NV;
+    const int v = (int)(i % NV);
+    *reinterpret_cast<uint4*>(dst + pix * ldd + off + v * EPC) =
+        *reinterpret_cast<const uint4*>(src + pix * lds_ + v * EPC);
+  }
+}
+
+// Fused classifier-free guidance + DDIM update, fp32 NCHW, n = B*C*H*W elements.
+//   e = e_u + g (e_c - e_u);  pred_x0 = (x - sqrt(1-a_t) e)/sqrt(a_t)
+//   x_prev = sqrt(a_prev) pred_x0 + sqrt(1-a_prev-sigma^2) e + sigma*temperature*noise
+// eps holds [cond ; uncond] halves (ddim.py:243,252: cond FIRST).
+__global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps_c,
+                                 const float* __restrict__ eps_u, const float* __restrict__ noise, long n,
+                                 float guidance, float a_t, float a_prev, float sqrt_one_minus_at, float sigma_t,
+                                 float temperature, float* __restrict__ x_prev, float* __restrict__ pred_x0) {
+  const float sqrt_at = sqrtf(a_t);
+  const float sqrt_aprev = sqrtf(a_prev);
+  const float dir_c = sqrtf(1.0f - a_prev - sigma_t * sigma_t);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float ec = eps_c[i];
+    float e = ec;
+    if (eps_u) {
+      const float eu = eps_u[i];
+      e = eu + guidance * (ec - eu);
+    }
+    const float xv = x[i];
+    const float p0 = (xv - sqrt_one_minus_at * e) / sqrt_at;
+    float xp = sqrt_aprev * p0 + dir_c * e;
+    if (noise) xp += sigma_t * noise[i] * temperature;
+    x_prev[i] = xp;
+    if (pred_x0) pred_x0[i] = p0;
+  }
+}
+
+// row softmax in place over fp32-accumulated T rows: x[row][0..n) (VAE AttnBlock)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(T* __restrict__ x, int ld, int ncols, long rows) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  if (row >= rows) return;
+  T* xr = x + row * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float mx = -INFINITY;
+  for (int c = tid; c < ncols; c += 256) mx = fmaxf(mx, to_f32<T>(xr[c]));
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = tid; c < ncols; c += 256) s += expf(to_f32<T>(xr[c]) - mx);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  s = red[0] + red[1] + red[2] + red[3];
+  const float inv = 1.0f / s;
+  for (int c = tid; c < ncols; c += 256) xr[c] = from_f32<T>(expf(to_f32<T>(xr[c]) - mx) * inv);
+}
+
+// y[b][c][r] = x[b][r][c]   (x: [B][R][ldx] take first Cn columns; y: [B][Cn][R])
+template <typename T>
+__global__ void transpose_kernel(const T* __restrict__ x, long x_bs, int ldx, T* __restrict__ y, long y_bs,
+                                 int R, int Cn) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < Cn) ? to_f32<T>(x[(long)b * x_bs + (long)r * ldx + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < R && c < Cn) y[(long)b * y_bs + (long)c * R + r] = from_f32<T>(tile[tx][i]);
+  }
+}
+
+// image post-process: NHWC T [B,HW,ld] (3 channels) -> uint8 HWC [B,HW,3]:
+//   clamp((x+1)/2, 0, 1) * 255, truncated (numpy astype(uint8)), stable_txt2img.py:715,764-765
+template <typename T>
+__global__ void to_uint8_kernel(const T* __restrict__ x, int ld, uint8_t* __restrict__ y, long npix) {
+  const long n = npix * 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / 3;
+    const int c = (int)(i % 3);
+    float f = (to_f32<T>(x[pix * ld + c]) + 1.0f) * 0.5f;
+    f = fminf(fmaxf(f, 0.f), 1.f);
+    y[i] = (uint8_t)(255.f * f);
+  }
+}
+// same post-process from an fp32 NCHW image [B,3,H,W] -> uint8 HWC
+__global__ void nchw_to_uint8_kernel(const float* __restrict__ x, uint8_t* __restrict__ y, int B, int HW) {
+  const long n = (long)B * HW * 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % 3);
+    const long bp = i / 3;
+    const int pix = (int)(bp % HW);
+    const long b = bp / HW;
+    float f = (x[(b * 3 + c) * HW + pix] + 1.0f) * 0.5f;
+    f = fminf(fmaxf(f, 0.f), 1.f);
+    y[i] = (uint8_t)(255.f * f);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------
+template <typename T>
+int af_launch_nchw_to_nhwc(const float* x, void* y, int B, int Cn, int HW, int Cpad, float scale, hipStream_t s) {
+  const long n = (long)B * HW * Cpad;
+  hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), EW_GRID(n), dim3(256), 0, s, x, reinterpret_cast<T*>(y), B, Cn, HW,
+                     Cpad, scale);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <typename T>
+int af_launch_nhwc_to_nchw(const void* x, float* y, int B, int Cn, int HW, int ld, hipStream_t s) {
+  const long n = (long)B * Cn * HW;
+  hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), EW_GRID(n), dim3(256), 0, s, reinterpret_cast<const T*>(x), y, B, Cn,
+                     HW, ld);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <typename T> int af_launch_cast_f32(const float* x, void* y, long n, hipStream_t s) {
+  hipLaunchKernelGGL((cast_f32_kernel<T>), EW_GRID(n), dim3(256), 0, s, x, reinterpret_cast<T*>(y), n);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <typename T> int af_launch_cast_to_f32(const void* x, float* y, long n, hipStream_t s) {
+  hipLaunchKernelGGL((cast_to_f32_kernel<T>), EW_GRID(n), dim3(256), 0, s, reinterpret_cast<const T*>(x), y, n);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <typename T> int af_launch_timestep_embedding(const long long* t, void* y, int B, int dim, hipStream_t s) {
+  hipLaunchKernelGGL((timestep_embedding_kernel<T>), EW_GRID((long)B * dim), dim3(256), 0, s, t,
+                     reinterpret_cast<T*>(y), B, dim);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <typename T> int af_launch_silu(const void* x, void* y, long n, hipStream_t s) {
+  hipLaunchKernelGGL((silu_kernel<T>), EW_GRID(n), dim3(256), 0, s, reinterpret_cast<const T*>(x),
+                     reinterpret_cast<T*>(y), n);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <typename T>
+int af_launch_copy_channels(const void* src, int lds_, void* dst, int ldd, int off, int Cn, long npix, hipStream_t s) {
+  constexpr int EPC = 16 / sizeof(T);
+  if (Cn % EPC || lds_ % EPC || ldd % EPC || off % EPC) {
+    af_set_error_msg("copy_channels: misaligned C=%d", Cn);
+    return -1;
+  }
+  const long n = npix * (Cn / EPC);
+  hipLaunchKernelGGL((copy_channels_kernel<T>), EW_GRID(n), dim3(256), 0, s, reinterpret_cast<const T*>(src), lds_,
+                     reinterpret_cast<T*>(dst), ldd, off, Cn, npix);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int af_launch_ddim_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, long n,
+                        float guidance, float a_t, float a_prev, float sqrt_one_minus_at, float sigma_t,
+                        float temperature, float* x_prev, float* pred_x0, hipStream_t s) {
+  hipLaunchKernelGGL(ddim_step_kernel, EW_GRID(n), dim3(256), 0, s, x, eps_c, eps_u, noise, n, guidance, a_t, a_prev,
+                     sqrt_one_minus_at, sigma_t, temperature, x_prev, pred_x0);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <typename T> int af_launch_softmax_rows(void* x, int ld, int ncols, long rows, hipStream_t s) {
+  hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3((unsigned)rows), dim3(256), 0, s, reinterpret_cast<T*>(x), ld,
+                     ncols, rows);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <typename T>
+int af_launch_transpose(const void* x, long x_bs, int ldx, void* y, long y_bs, int R, int Cn, int B, hipStream_t s) {
+  dim3 grid((R + 31) / 32, (Cn + 31) / 32, B);
+  hipLaunchKernelGGL((transpose_kernel<T>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(x), x_bs, ldx,
+                     reinterpret_cast<T*>(y), y_bs, R, Cn);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <typename T> int af_launch_to_uint8(const void* x, int ld, uint8_t* y, long npix, hipStream_t s) {
+  hipLaunchKernelGGL((to_uint8_kernel<T>), EW_GRID(npix * 3), dim3(256), 0, s, reinterpret_cast<const T*>(x), ld, y,
+                     npix);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int af_launch_nchw_to_uint8(const float* x, uint8_t* y, int B, int HW, hipStream_t s) {
+  hipLaunchKernelGGL(nchw_to_uint8_kernel, EW_GRID((long)B * HW * 3), dim3(256), 0, s, x, y, B, HW);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+#define INST(T)                                                                                               \
+  template int af_launch_nchw_to_nhwc<T>(const float*, void*, int, int, int, int, float, hipStream_t);        \
+  template int af_launch_nhwc_to_nchw<T>(const void*, float*, int, int, int, int, hipStream_t);               \
+  template int af_launch_cast_f32<T>(const float*, void*, long, hipStream_t);                                 \
+  template int af_launch_cast_to_f32<T>(const void*, float*, long, hipStream_t);                              \
+  template int af_launch_timestep_embedding<T>(const long long*, void*, int, int, hipStream_t);               \
+  template int af_launch_silu<T>(const void*, void*, long, hipStream_t);                                      \
+  template int af_launch_copy_channels<T>(const void*, int, void*, int, int, int, long, hipStream_t);         \
+  template int af_launch_softmax_rows<T>(void*, int, int, long, hipStream_t);                                 \
+  template int af_launch_transpose<T>(const void*, long, int, void*, long, int, int, int, hipStream_t);       \
+  template int af_launch_to_uint8<T>(const void*, int, uint8_t*, long, hipStream_t);
+INST(bf16)
+INST(float)
+
+// ---------------------------------------------------------------------------
+// weight repack: [rows][cin][ks][ks] fp32 -> T [row_off + perm(n)][(ky,kx,c) with c padded to cin_pad]
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int geglu_perm(int n, int half) {
+  const int j = n < half ? n : n - half;
+  return (j >> 5) * 64 + (n < half ? 0 : 32) + (j & 31);
+}
+template <typename T>
+__global__ void repack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int cin,
+                                     int cin_pad, int ks, int ldw, int row_off, int perm) {
+  const int kk = ks * ks;
+  const long n = (long)rows * kk * cin_pad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cin_pad);
+    const long t = i / cin_pad;
+    const int tap = (int)(t % kk);
+    const int r = (int)(t / kk);
+    float v = 0.f;
+    if (c < cin) v = src[((long)r * cin + c) * kk + tap];
+    const int rr = perm ? geglu_perm(r, rows >> 1) : r;
+    dst[(long)(row_off + rr) * ldw + tap * cin_pad + c] = from_f32<T>(v);
+  }
+}
+__global__ void permute_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int perm) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x)
+    dst[perm ? geglu_perm(i, rows >> 1) : i] = src[i];
+}
+template <typename T>
+int af_launch_repack_weight(const float* src, void* dst, int rows, int cin, int cin_pad, int ks, int ldw, int row_off,
+                            int perm, hipStream_t s) {
+  const long n = (long)rows * ks * ks * cin_pad;
+  hipLaunchKernelGGL((repack_weight_kernel<T>), EW_GRID(n), dim3(256), 0, s, src, reinterpret_cast<T*>(dst), rows, cin,
+                     cin_pad, ks, ldw, row_off, perm);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int af_launch_permute_bias(const float* src, float* dst, int rows, int perm, hipStream_t s) {
+  hipLaunchKernelGGL(permute_bias_kernel, EW_GRID(rows), dim3(256), 0, s, src, dst, rows, perm);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template int af_launch_repack_weight<bf16>(const float*, void*, int, int, int, int, int, int, int, hipStream_t);
+template int af_launch_repack_weight<float>(const float*, void*, int, int, int, int, int, int, int, hipStream_t);

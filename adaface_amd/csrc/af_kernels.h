@@ -1,0 +1,40 @@
+// Internal launcher declarations (one template per storage type T = bf16 | float).
+#pragma once
+#include "af_common.h"
+
+template <typename T> int af_launch_conv_gemm(const ConvGemmParams& p, int batch, hipStream_t stream);
+template <typename T> int af_launch_attention(const AttnParams& p, int B, int dh, hipStream_t stream);
+
+size_t af_gn_workspace_bytes(int B, int HW);
+template <typename T>
+int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn, const float* gamma,
+                        const float* beta, float eps, int silu, void* y, long y_bs, int ldy, void* workspace,
+                        hipStream_t stream);
+template <typename T>
+int af_launch_layernorm(const void* x, int ldx, long rows, int Cn, const float* gamma, const float* beta,
+                        float eps, void* y, int ldy, hipStream_t stream);
+
+template <typename T>
+int af_launch_nchw_to_nhwc(const float* x, void* y, int B, int Cn, int HW, int Cpad, float scale, hipStream_t s);
+template <typename T> int af_launch_nhwc_to_nchw(const void* x, float* y, int B, int Cn, int HW, int ld, hipStream_t s);
+template <typename T> int af_launch_cast_f32(const float* x, void* y, long n, hipStream_t s);
+template <typename T> int af_launch_cast_to_f32(const void* x, float* y, long n, hipStream_t s);
+template <typename T> int af_launch_timestep_embedding(const long long* t, void* y, int B, int dim, hipStream_t s);
+template <typename T> int af_launch_silu(const void* x, void* y, long n, hipStream_t s);
+template <typename T>
+int af_launch_copy_channels(const void* src, int lds_, void* dst, int ldd, int off, int Cn, long npix, hipStream_t s);
+int af_launch_ddim_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, long n,
+                        float guidance, float a_t, float a_prev, float sqrt_one_minus_at, float sigma_t,
+                        float temperature, float* x_prev, float* pred_x0, hipStream_t s);
+template <typename T> int af_launch_softmax_rows(void* x, int ld, int ncols, long rows, hipStream_t s);
+template <typename T>
+int af_launch_transpose(const void* x, long x_bs, int ldx, void* y, long y_bs, int R, int Cn, int B, hipStream_t s);
+template <typename T> int af_launch_to_uint8(const void* x, int ld, uint8_t* y, long npix, hipStream_t s);
+int af_launch_nchw_to_uint8(const float* x, uint8_t* y, int B, int HW, hipStream_t s);
+
+// weight repack (device): src fp32 [rows][cin][ks][ks] -> dst T rows [row_off + perm(n)][ks*ks*cin_pad]
+//   perm: 0 identity, 1 GEGLU interleave (value/gate groups of 32, half = rows/2)
+template <typename T>
+int af_launch_repack_weight(const float* src, void* dst, int rows, int cin, int cin_pad, int ks, int ldw, int row_off,
+                            int perm, hipStream_t s);
+int af_launch_permute_bias(const float* src, float* dst, int rows, int perm, hipStream_t s);

@@ -1,0 +1,1124 @@
+// Host-side model assembly and executors for the denoising path, plus the C ABI.
+//
+//   UNet   : UNetModel.__init__/forward      ldm/modules/diffusionmodules/openaimodel.py:447-703, 827-1052
+//            ResBlock._forward               openaimodel.py:259-279
+//            SpatialTransformer.forward      ldm/modules/attention.py:321-341
+//            BasicTransformerBlock._forward  attention.py:275-285
+//            CrossAttention.forward          attention.py:172-257
+//            FeedForward / GEGLU             attention.py:32-59
+//   VAE    : Decoder.forward                 ldm/modules/diffusionmodules/model.py:575-608
+//            ResnetBlock / AttnBlock         model.py:122-142, 179-242
+//            AutoencoderKL.decode            ldm/models/autoencoder.py:330-333
+//
+// Everything here is plumbing around the kernels in af_conv_gemm / af_attention /
+// af_norm / af_elementwise: it derives the block structure from the constructor
+// arguments exactly as the reference constructor does, owns the repacked weights and
+// an activation arena in HBM, and enqueues the kernels on the caller's stream.
+// No CPU fallback exists: every op is a HIP kernel launch.
+#include "../../include/adaface_hip.h"
+#include "af_kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+// ----------------------------------------------------------------------------
+// error handling
+// ----------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void af_set_error_msg(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+#define AF_TRY(expr)            \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != 0) return _rc;   \
+  } while (0)
+
+static inline size_t esize(int dtype) { return dtype == AF_DTYPE_BF16 ? 2 : 4; }
+static inline int bk_of(int dtype) { return dtype == AF_DTYPE_BF16 ? 64 : 32; }
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+#define DISPATCH(dtype, CALL_BF16, CALL_F32) ((dtype) == AF_DTYPE_BF16 ? (CALL_BF16) : (CALL_F32))
+
+// ----------------------------------------------------------------------------
+// activation arena (bump allocator with mark/release); dry mode only measures.
+// ----------------------------------------------------------------------------
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, peak = 0;
+  bool dry = false;
+  void* alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    size_t o = off;
+    off += bytes;
+    if (off > peak) peak = off;
+    if (dry) return reinterpret_cast<void*>((uintptr_t)0x1000 + o);  // never dereferenced
+    if (off > cap) return nullptr;
+    return base + o;
+  }
+  size_t mark() const { return off; }
+  void release(size_t m) { off = m; }
+};
+
+struct Act {  // NHWC activation view
+  void* p = nullptr;
+  int B = 0, H = 0, W = 0, C = 0;
+  int ld = 0;  // elements between pixels
+  long npix() const { return (long)B * H * W; }
+};
+
+// ----------------------------------------------------------------------------
+// weights
+// ----------------------------------------------------------------------------
+struct Linear {  // conv or linear weight, repacked [rows_pad][ldw] in storage dtype
+  void* w = nullptr;
+  float* bias = nullptr;
+  int cin = 0, cin_pad = 0, cout = 0, ks = 1, rows_pad = 0, ldw = 0;
+  bool geglu = false;
+};
+struct Norm {
+  float* gamma = nullptr;
+  float* beta = nullptr;
+  int C = 0;
+  float eps = 1e-5f;
+};
+struct ResBlockW {
+  Norm n1, n2;
+  Linear c1, c2, skip;
+  bool has_skip = false;
+  int cin = 0, cout = 0;
+  int emb_off = -1;  // column offset in the fused emb_layers output (UNet only)
+};
+struct XfmrBlockW {
+  Norm ln1, ln2, ln3;
+  Linear qkv1, out1, q2, kv2, out2, ff1, ff2;
+};
+struct XfmrW {
+  int C = 0, heads = 0, dh = 0;
+  Norm gn;
+  Linear proj_in, proj_out;
+  std::vector<XfmrBlockW> blocks;
+  int ca_slot = -1;  // index into the cached context K/V list (first block of this transformer)
+};
+struct VaeAttnW {
+  Norm gn;
+  Linear qkv, proj_out;
+  int C = 0;
+};
+enum LayerKind { L_CONV_IN, L_RES, L_XFMR, L_DOWN, L_UP };
+struct LayerRef {
+  LayerKind kind;
+  int idx;
+};
+struct UBlock {
+  std::vector<LayerRef> layers;
+};
+
+struct Slot {  // one expected state_dict tensor
+  enum Kind { WEIGHT, BIAS_VEC } kind = WEIGHT;
+  std::vector<int64_t> shape;
+  // WEIGHT: destination rows in a (possibly fused) repacked buffer
+  void* dst = nullptr;
+  int rows = 0, cin = 0, cin_pad = 0, ks = 1, ldw = 0, row_off = 0, perm = 0;
+  // BIAS_VEC: fp32 vector (optionally permuted) at dst_f
+  float* dst_f = nullptr;
+  bool loaded = false;
+};
+
+struct CtxKV {  // cached cross-attention K/V for one transformer block
+  void* kv = nullptr;  // [Bf*n_tokens][2*C]
+  int C = 0;
+};
+
+struct af_handle {
+  int device = 0;
+  af_config cfg;
+  int dtype = 0;
+  std::vector<void*> owned;  // hipMalloc'd weight buffers
+  std::map<std::string, Slot> slots;
+  std::vector<std::string> slot_names;
+
+  // UNet
+  Linear time_embed0, time_embed2, emb_all;
+  int emb_total = 0;
+  Linear conv_in;
+  std::vector<ResBlockW> res;
+  std::vector<XfmrW> xf;
+  std::vector<Linear> updown;
+  std::vector<UBlock> input_blocks, output_blocks;
+  UBlock middle_block;
+  Norm out_norm;
+  Linear out_conv;
+  std::vector<std::pair<int, int>> ca_list;  // (xfmr index, block index) in layer order
+
+  // VAE
+  Linear post_quant, vae_conv_in, vae_conv_out;
+  Norm vae_norm_out;
+  std::vector<ResBlockW> vres;
+  VaeAttnW vattn;
+  std::vector<Linear> vup;
+  struct VLevel { std::vector<int> blocks; int up = -1; };
+  int vmid1 = -1, vmid2 = -1;
+  std::vector<VLevel> vlevels;  // index = i_level
+
+  // runtime state
+  Arena arena;
+  float* stage = nullptr;  // fp32 staging for weight upload
+  size_t stage_bytes = 0;
+  std::vector<CtxKV> ctx_kv;
+  void* ctx_cast = nullptr;
+  size_t ctx_cast_bytes = 0;
+  int ctx_Bf = 0, ctx_tokens = 0;
+  bool ctx_set = false;
+};
+
+// ----------------------------------------------------------------------------
+// model construction helpers
+// ----------------------------------------------------------------------------
+struct Builder {
+  af_handle* h;
+  int rc = 0;
+  void* dmalloc(size_t bytes, bool zero = true) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      af_set_error_msg("hipMalloc(%zu) failed", bytes);
+      rc = AF_ERR_HIP;
+      return nullptr;
+    }
+    if (zero) hipMemset(p, 0, bytes);
+    h->owned.push_back(p);
+    return p;
+  }
+  void add_slot(const std::string& name, const Slot& s) {
+    h->slots[name] = s;
+    h->slot_names.push_back(name);
+  }
+  // allocate a repacked weight buffer of `rows` x (ks*ks*cin_pad)
+  void alloc_linear(Linear& L, int cin, int cout_rows, int ks, bool pad_cin) {
+    const int bk = bk_of(h->dtype);
+    L.cin = cin;
+    L.cin_pad = pad_cin ? round_up(cin, bk) : cin;
+    L.ks = ks;
+    L.cout = cout_rows;
+    L.rows_pad = round_up(cout_rows, 128);
+    L.ldw = ks * ks * L.cin_pad;
+    L.w = dmalloc((size_t)L.rows_pad * L.ldw * esize(h->dtype));
+  }
+  void weight_slot(const std::string& name, Linear& L, int rows, int row_off, int perm, bool conv_shape) {
+    Slot s;
+    s.kind = Slot::WEIGHT;
+    if (conv_shape) s.shape = {rows, L.cin, L.ks, L.ks};
+    else s.shape = {rows, L.cin};
+    s.dst = L.w;
+    s.rows = rows;
+    s.cin = L.cin;
+    s.cin_pad = L.cin_pad;
+    s.ks = L.ks;
+    s.ldw = L.ldw;
+    s.row_off = row_off;
+    s.perm = perm;
+    add_slot(name, s);
+  }
+  void vec_slot(const std::string& name, float* dst, int n, int perm = 0) {
+    Slot s;
+    s.kind = Slot::BIAS_VEC;
+    s.shape = {n};
+    s.dst_f = dst;
+    s.rows = n;
+    s.perm = perm;
+    add_slot(name, s);
+  }
+  float* alloc_vec(int n) { return reinterpret_cast<float*>(dmalloc((size_t)round_up(n, 128) * sizeof(float))); }
+
+  // nn.Conv2d / nn.Linear with weight+bias under `prefix`
+  void make_conv(Linear& L, const std::string& prefix, int cin, int cout, int ks, bool bias = true,
+                 bool conv_shape = true, bool pad_cin = false) {
+    alloc_linear(L, cin, cout, ks, pad_cin);
+    weight_slot(prefix + ".weight", L, cout, 0, 0, conv_shape);
+    if (bias) {
+      L.bias = alloc_vec(cout);
+      vec_slot(prefix + ".bias", L.bias, cout);
+    }
+  }
+  void make_norm(Norm& N, const std::string& prefix, int C, float eps) {
+    N.C = C;
+    N.eps = eps;
+    N.gamma = alloc_vec(C);
+    N.beta = alloc_vec(C);
+    vec_slot(prefix + ".weight", N.gamma, C);
+    vec_slot(prefix + ".bias", N.beta, C);
+  }
+};
+
+// ResBlock (openaimodel.py:183-245): in_layers.{0,2}, emb_layers.1, out_layers.{0,3}, skip_connection
+static int make_unet_resblock(Builder& b, const std::string& prefix, int cin, int cout) {
+  af_handle* h = b.h;
+  ResBlockW r;
+  r.cin = cin;
+  r.cout = cout;
+  b.make_norm(r.n1, prefix + ".in_layers.0", cin, 1e-5f);
+  b.make_conv(r.c1, prefix + ".in_layers.2", cin, cout, 3);
+  r.emb_off = h->emb_total;
+  h->emb_total += cout;
+  b.make_norm(r.n2, prefix + ".out_layers.0", cout, 1e-5f);
+  b.make_conv(r.c2, prefix + ".out_layers.3", cout, cout, 3);
+  if (cin != cout) {
+    r.has_skip = true;
+    b.make_conv(r.skip, prefix + ".skip_connection", cin, cout, 1);
+  }
+  h->res.push_back(r);
+  return (int)h->res.size() - 1;
+}
+
+// SpatialTransformer (attention.py:294-317) with `depth` BasicTransformerBlocks
+static int make_xfmr(Builder& b, const std::string& prefix, int C, int heads, int dh, int depth, int ctx_dim) {
+  af_handle* h = b.h;
+  XfmrW x;
+  x.C = C;
+  x.heads = heads;
+  x.dh = dh;
+  const int inner = heads * dh;
+  b.make_norm(x.gn, prefix + ".norm", C, 1e-6f);
+  b.make_conv(x.proj_in, prefix + ".proj_in", C, inner, 1);
+  for (int d = 0; d < depth; ++d) {
+    XfmrBlockW t;
+    const std::string p = prefix + ".transformer_blocks." + std::to_string(d);
+    b.make_norm(t.ln1, p + ".norm1", inner, 1e-5f);
+    b.make_norm(t.ln2, p + ".norm2", inner, 1e-5f);
+    b.make_norm(t.ln3, p + ".norm3", inner, 1e-5f);
+    // attn1: fused q|k|v rows (no bias, attention.py:157-159)
+    b.alloc_linear(t.qkv1, inner, 3 * inner, 1, false);
+    b.weight_slot(p + ".attn1.to_q.weight", t.qkv1, inner, 0, 0, false);
+    b.weight_slot(p + ".attn1.to_k.weight", t.qkv1, inner, inner, 0, false);
+    b.weight_slot(p + ".attn1.to_v.weight", t.qkv1, inner, 2 * inner, 0, false);
+    b.make_conv(t.out1, p + ".attn1.to_out.0", inner, inner, 1, true, false);
+    // attn2: q from x, fused k|v from the context
+    b.make_conv(t.q2, p + ".attn2.to_q", inner, inner, 1, false, false);
+    b.alloc_linear(t.kv2, ctx_dim, 2 * inner, 1, false);
+    b.weight_slot(p + ".attn2.to_k.weight", t.kv2, inner, 0, 0, false);
+    b.weight_slot(p + ".attn2.to_v.weight", t.kv2, inner, inner, 0, false);
+    b.make_conv(t.out2, p + ".attn2.to_out.0", inner, inner, 1, true, false);
+    // ff: GEGLU proj (value|gate rows interleaved in groups of 32) + out linear
+    b.alloc_linear(t.ff1, inner, 8 * inner, 1, false);
+    t.ff1.geglu = true;
+    b.weight_slot(p + ".ff.net.0.proj.weight", t.ff1, 8 * inner, 0, 1, false);
+    t.ff1.bias = b.alloc_vec(8 * inner);
+    b.vec_slot(p + ".ff.net.0.proj.bias", t.ff1.bias, 8 * inner, 1);
+    b.make_conv(t.ff2, p + ".ff.net.2", 4 * inner, inner, 1, true, false);
+    x.blocks.push_back(t);
+  }
+  b.make_conv(x.proj_out, prefix + ".proj_out", inner, C, 1);
+  h->xf.push_back(x);
+  return (int)h->xf.size() - 1;
+}
+
+static bool in_list(const int* a, int n, int v) {
+  for (int i = 0; i < n; ++i)
+    if (a[i] == v) return true;
+  return false;
+}
+
+// mirrors UNetModel.__init__ (openaimodel.py:517-697)
+static int build_unet(Builder& b) {
+  af_handle* h = b.h;
+  const af_config& c = h->cfg;
+  const int mc = c.model_channels, ted = mc * 4;
+  const std::string P = "model.diffusion_model.";
+  if (mc % bk_of(h->dtype) != 0 || c.context_dim % bk_of(h->dtype) != 0 || c.num_heads <= 0) {
+    af_set_error_msg("unet: model_channels (%d) and context_dim (%d) must be multiples of %d", mc, c.context_dim,
+                     bk_of(h->dtype));
+    return AF_ERR_INVALID;
+  }
+  b.make_conv(h->time_embed0, P + "time_embed.0", mc, ted, 1, true, false);
+  b.make_conv(h->time_embed2, P + "time_embed.2", ted, ted, 1, true, false);
+
+  auto add_xfmr = [&](UBlock& ub, const std::string& prefix, int ch) {
+    const int dh = ch / c.num_heads;
+    int xi = make_xfmr(b, prefix, ch, c.num_heads, dh, c.transformer_depth, c.context_dim);
+    ub.layers.push_back({L_XFMR, xi});
+  };
+
+  {  // input_blocks.0
+    UBlock ub;
+    b.make_conv(h->conv_in, P + "input_blocks.0.0", c.in_channels, mc, 3, true, true, /*pad_cin=*/true);
+    ub.layers.push_back({L_CONV_IN, 0});
+    h->input_blocks.push_back(ub);
+  }
+  std::vector<int> chans = {mc};
+  int ch = mc, ds = 1;
+  for (int level = 0; level < c.n_channel_mult; ++level) {
+    const int mult = c.channel_mult[level];
+    for (int r = 0; r < c.num_res_blocks; ++r) {
+      UBlock ub;
+      const std::string pre = P + "input_blocks." + std::to_string(h->input_blocks.size());
+      int ri = make_unet_resblock(b, pre + ".0", ch, mult * mc);
+      ub.layers.push_back({L_RES, ri});
+      ch = mult * mc;
+      if (in_list(c.attention_resolutions, c.n_attention_resolutions, ds)) add_xfmr(ub, pre + ".1", ch);
+      h->input_blocks.push_back(ub);
+      chans.push_back(ch);
+    }
+    if (level != c.n_channel_mult - 1) {
+      UBlock ub;
+      const std::string pre = P + "input_blocks." + std::to_string(h->input_blocks.size());
+      Linear d;
+      b.make_conv(d, pre + ".0.op", ch, ch, 3);
+      h->updown.push_back(d);
+      ub.layers.push_back({L_DOWN, (int)h->updown.size() - 1});
+      h->input_blocks.push_back(ub);
+      chans.push_back(ch);
+      ds *= 2;
+    }
+  }
+  {  // middle_block
+    UBlock& ub = h->middle_block;
+    int r0 = make_unet_resblock(b, P + "middle_block.0", ch, ch);
+    ub.layers.push_back({L_RES, r0});
+    add_xfmr(ub, P + "middle_block.1", ch);
+    int r2 = make_unet_resblock(b, P + "middle_block.2", ch, ch);
+    ub.layers.push_back({L_RES, r2});
+  }
+  for (int level = c.n_channel_mult - 1; level >= 0; --level) {
+    const int mult = c.channel_mult[level];
+    for (int i = 0; i < c.num_res_blocks + 1; ++i) {
+      UBlock ub;
+      const std::string pre = P + "output_blocks." + std::to_string(h->output_blocks.size());
+      const int ich = chans.back();
+      chans.pop_back();
+      int ri = make_unet_resblock(b, pre + ".0", ch + ich, mc * mult);
+      ub.layers.push_back({L_RES, ri});
+      ch = mc * mult;
+      int li = 1;
+      if (in_list(c.attention_resolutions, c.n_attention_resolutions, ds)) {
+        add_xfmr(ub, pre + "." + std::to_string(li), ch);
+        ++li;
+      }
+      if (level && i == c.num_res_blocks) {
+        Linear u;
+        b.make_conv(u, pre + "." + std::to_string(li) + ".conv", ch, ch, 3);
+        h->updown.push_back(u);
+        ub.layers.push_back({L_UP, (int)h->updown.size() - 1});
+        ds /= 2;
+      }
+      h->output_blocks.push_back(ub);
+    }
+  }
+  b.make_norm(h->out_norm, P + "out.0", ch, 1e-5f);
+  b.make_conv(h->out_conv, P + "out.2", mc, c.out_channels, 3);
+
+  // fused emb_layers.1 of every ResBlock: one [emb_total, ted] linear
+  b.alloc_linear(h->emb_all, ted, h->emb_total, 1, false);
+  h->emb_all.bias = b.alloc_vec(h->emb_total);
+  auto emb_slots = [&](const UBlock& ub, const std::string& pre) {
+    for (size_t li = 0; li < ub.layers.size(); ++li) {
+      if (ub.layers[li].kind != L_RES) continue;
+      ResBlockW& r = h->res[ub.layers[li].idx];
+      const std::string p = pre + "." + std::to_string(li) + ".emb_layers.1";
+      b.weight_slot(p + ".weight", h->emb_all, r.cout, r.emb_off, 0, false);
+      b.vec_slot(p + ".bias", h->emb_all.bias + r.emb_off, r.cout);
+    }
+  };
+  for (size_t i = 0; i < h->input_blocks.size(); ++i) emb_slots(h->input_blocks[i], P + "input_blocks." + std::to_string(i));
+  emb_slots(h->middle_block, P + "middle_block");
+  for (size_t i = 0; i < h->output_blocks.size(); ++i) emb_slots(h->output_blocks[i], P + "output_blocks." + std::to_string(i));
+
+  // cross-attention layers in forward order (input, middle, output)
+  auto collect_ca = [&](const UBlock& ub) {
+    for (auto& l : ub.layers)
+      if (l.kind == L_XFMR) {
+        h->xf[l.idx].ca_slot = (int)h->ca_list.size();
+        for (size_t d = 0; d < h->xf[l.idx].blocks.size(); ++d) h->ca_list.push_back({l.idx, (int)d});
+      }
+  };
+  for (auto& ub : h->input_blocks) collect_ca(ub);
+  collect_ca(h->middle_block);
+  for (auto& ub : h->output_blocks) collect_ca(ub);
+  h->ctx_kv.resize(h->ca_list.size());
+  return b.rc;
+}
+
+// ResnetBlock (model.py:83-142), temb_channels = 0
+static int make_vae_resblock(Builder& b, const std::string& prefix, int cin, int cout) {
+  af_handle* h = b.h;
+  ResBlockW r;
+  r.cin = cin;
+  r.cout = cout;
+  b.make_norm(r.n1, prefix + ".norm1", cin, 1e-6f);
+  b.make_conv(r.c1, prefix + ".conv1", cin, cout, 3);
+  b.make_norm(r.n2, prefix + ".norm2", cout, 1e-6f);
+  b.make_conv(r.c2, prefix + ".conv2", cout, cout, 3);
+  if (cin != cout) {
+    r.has_skip = true;
+    b.make_conv(r.skip, prefix + ".nin_shortcut", cin, cout, 1);
+  }
+  h->vres.push_back(r);
+  return (int)h->vres.size() - 1;
+}
+
+// mirrors Decoder.__init__ (model.py:502-573) + post_quant_conv (autoencoder.py:305)
+static int build_vae(Builder& b) {
+  af_handle* h = b.h;
+  const af_config& c = h->cfg;
+  const std::string P = "first_stage_model.";
+  const int nres = c.n_vae_ch_mult;
+  int block_in = c.vae_ch * c.vae_ch_mult[nres - 1];
+  if (c.vae_ch % bk_of(h->dtype) != 0 && c.vae_ch % 32 != 0) {
+    af_set_error_msg("vae: ch must be a multiple of 32");
+    return AF_ERR_INVALID;
+  }
+  b.make_conv(h->post_quant, P + "post_quant_conv", c.vae_embed_dim, c.vae_z_channels, 1, true, true, true);
+  b.make_conv(h->vae_conv_in, P + "decoder.conv_in", c.vae_z_channels, block_in, 3, true, true, true);
+  h->vmid1 = make_vae_resblock(b, P + "decoder.mid.block_1", block_in, block_in);
+  {
+    VaeAttnW& a = h->vattn;
+    a.C = block_in;
+    const std::string p = P + "decoder.mid.attn_1";
+    b.make_norm(a.gn, p + ".norm", block_in, 1e-6f);
+    b.alloc_linear(a.qkv, block_in, 3 * block_in, 1, false);
+    a.qkv.bias = b.alloc_vec(3 * block_in);
+    const char* nm[3] = {".q", ".k", ".v"};
+    for (int i = 0; i < 3; ++i) {
+      b.weight_slot(p + nm[i] + ".weight", a.qkv, block_in, i * block_in, 0, true);
+      b.vec_slot(p + nm[i] + ".bias", a.qkv.bias + i * block_in, block_in);
+    }
+    b.make_conv(a.proj_out, p + ".proj_out", block_in, block_in, 1);
+  }
+  h->vmid2 = make_vae_resblock(b, P + "decoder.mid.block_2", block_in, block_in);
+  h->vlevels.resize(nres);
+  for (int lvl = nres - 1; lvl >= 0; --lvl) {
+    const int block_out = c.vae_ch * c.vae_ch_mult[lvl];
+    const std::string pl = P + "decoder.up." + std::to_string(lvl);
+    for (int i = 0; i < c.vae_num_res_blocks + 1; ++i) {
+      int ri = make_vae_resblock(b, pl + ".block." + std::to_string(i), block_in, block_out);
+      h->vlevels[lvl].blocks.push_back(ri);
+      block_in = block_out;
+    }
+    if (lvl != 0) {
+      Linear u;
+      b.make_conv(u, pl + ".upsample.conv", block_in, block_in, 3);
+      h->vup.push_back(u);
+      h->vlevels[lvl].up = (int)h->vup.size() - 1;
+    }
+  }
+  b.make_norm(h->vae_norm_out, P + "decoder.norm_out", block_in, 1e-6f);
+  b.make_conv(h->vae_conv_out, P + "decoder.conv_out", block_in, c.vae_out_ch, 3);
+  return b.rc;
+}
+
+// ----------------------------------------------------------------------------
+// op runner: thin typed dispatch + arena allocation
+// ----------------------------------------------------------------------------
+struct Runner {
+  af_handle* h;
+  hipStream_t s;
+  int dt;
+  bool dry;
+  Arena& A;
+  Runner(af_handle* h_, hipStream_t s_) : h(h_), s(s_), dt(h_->dtype), dry(h_->arena.dry), A(h_->arena) {}
+
+  Act alloc_act(int B, int H, int W, int C, int ld = 0) {
+    Act a;
+    a.B = B; a.H = H; a.W = W; a.C = C;
+    a.ld = ld ? ld : C;
+    a.p = A.alloc((size_t)a.npix() * a.ld * esize(dt));
+    return a;
+  }
+  int check(const Act& a) {
+    if (!a.p) {
+      af_set_error_msg("activation arena exhausted (cap %zu)", A.cap);
+      return AF_ERR_STATE;
+    }
+    return 0;
+  }
+
+  // conv / linear.  out must be preallocated.  up: nearest 2x before the conv.
+  int conv(const Linear& L, const Act& x, Act& out, int stride, int up, const Act* residual, const void* rowbias,
+           int ldrb, int n_valid = -1) {
+    AF_TRY(check(out));
+    if (dry) return 0;
+    ConvGemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.src = x.p;
+    p.src_batch_stride = (long)x.H * x.W * x.ld;
+    p.ldc = x.ld;
+    p.Cin = L.cin_pad;
+    p.Hs = x.H; p.Ws = x.W;
+    p.up = up;
+    p.Hi = x.H << up; p.Wi = x.W << up;
+    p.Ho = out.H; p.Wo = out.W;
+    p.ks = L.ks; p.stride = stride; p.pad = L.ks / 2;
+    p.W = L.w; p.ldw = L.ldw; p.Wrows = L.rows_pad;
+    p.M = (int)out.npix();
+    p.N = n_valid > 0 ? n_valid : round_up(L.cout, 4);
+    p.K = L.ldw;
+    p.bias = L.bias;
+    p.rowbias = rowbias; p.ldrb = ldrb;
+    p.residual = residual ? residual->p : nullptr;
+    p.ldr = residual ? residual->ld : 0;
+    p.out = out.p; p.ldo = out.ld;
+    p.epilogue = L.geglu ? AF_EPI_GEGLU : AF_EPI_NONE;
+    p.alpha = 1.0f;
+    if (x.C < L.cin || x.ld < L.cin_pad) {
+      af_set_error_msg("conv: input has %d channels (ld %d), layer expects %d (padded %d)", x.C, x.ld, L.cin, L.cin_pad);
+      return AF_ERR_INVALID;
+    }
+    return DISPATCH(dt, af_launch_conv_gemm<bf16>(p, 1, s), af_launch_conv_gemm<float>(p, 1, s));
+  }
+  int gemm_raw(const ConvGemmParams& p, int batch) {
+    if (dry) return 0;
+    return DISPATCH(dt, af_launch_conv_gemm<bf16>(p, batch, s), af_launch_conv_gemm<float>(p, batch, s));
+  }
+  int groupnorm(const Norm& N, const Act& x, Act& y, int silu) {
+    AF_TRY(check(y));
+    const int HW = x.H * x.W;
+    void* ws = A.alloc(af_gn_workspace_bytes(x.B, HW));
+    if (!ws) { af_set_error_msg("arena exhausted (groupnorm workspace)"); return AF_ERR_STATE; }
+    if (dry) return 0;
+    if (x.C != N.C) { af_set_error_msg("groupnorm: C mismatch %d vs %d", x.C, N.C); return AF_ERR_INVALID; }
+    return DISPATCH(dt,
+                    af_launch_groupnorm<bf16>(x.p, (long)HW * x.ld, x.ld, x.B, HW, x.C, N.gamma, N.beta, N.eps, silu,
+                                              y.p, (long)HW * y.ld, y.ld, ws, s),
+                    af_launch_groupnorm<float>(x.p, (long)HW * x.ld, x.ld, x.B, HW, x.C, N.gamma, N.beta, N.eps, silu,
+                                               y.p, (long)HW * y.ld, y.ld, ws, s));
+  }
+  int layernorm(const Norm& N, const Act& x, Act& y) {
+    AF_TRY(check(y));
+    if (dry) return 0;
+    return DISPATCH(dt, af_launch_layernorm<bf16>(x.p, x.ld, x.npix(), x.C, N.gamma, N.beta, N.eps, y.p, y.ld, s),
+                    af_launch_layernorm<float>(x.p, x.ld, x.npix(), x.C, N.gamma, N.beta, N.eps, y.p, y.ld, s));
+  }
+  int attention(const void* q, int ldq, long bsq, const void* k, int ldk, long bsk, const void* v, int ldv, long bsv,
+                Act& o, int Nq, int Nk, int heads, int dh) {
+    AF_TRY(check(o));
+    if (dry) return 0;
+    AttnParams p;
+    p.q = q; p.k = k; p.v = v; p.o = o.p;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = o.ld;
+    p.bsq = bsq; p.bsk = bsk; p.bsv = bsv; p.bso = (long)Nq * o.ld;
+    p.Nq = Nq; p.Nk = Nk; p.H = heads;
+    p.scale = 1.0f / sqrtf((float)dh);
+    return DISPATCH(dt, af_launch_attention<bf16>(p, o.B, dh, s), af_launch_attention<float>(p, o.B, dh, s));
+  }
+  int copy_channels(const Act& src, Act& dst, int off) {
+    if (dry) return 0;
+    return DISPATCH(dt, af_launch_copy_channels<bf16>(src.p, src.ld, dst.p, dst.ld, off, src.C, src.npix(), s),
+                    af_launch_copy_channels<float>(src.p, src.ld, dst.p, dst.ld, off, src.C, src.npix(), s));
+  }
+  char* elem_ptr(void* p, long off) { return reinterpret_cast<char*>(p) + off * (long)esize(dt); }
+};
+
+// ResBlock._forward (openaimodel.py:259-279) / ResnetBlock.forward (model.py:122-142)
+static int run_resblock(Runner& R, const ResBlockW& w, const Act& x, Act& out, const void* emb_all, int emb_ld) {
+  const size_t mk = R.A.mark();
+  Act t1 = R.alloc_act(x.B, x.H, x.W, x.C);
+  AF_TRY(R.groupnorm(w.n1, x, t1, 1));
+  Act t2 = R.alloc_act(x.B, x.H, x.W, w.cout);
+  const void* rb = (emb_all && w.emb_off >= 0) ? R.elem_ptr(const_cast<void*>(emb_all), w.emb_off) : nullptr;
+  AF_TRY(R.conv(w.c1, t1, t2, 1, 0, nullptr, rb, emb_ld));
+  Act t3 = R.alloc_act(x.B, x.H, x.W, w.cout);
+  AF_TRY(R.groupnorm(w.n2, t2, t3, 1));
+  Act sk = x;
+  if (w.has_skip) {
+    sk = R.alloc_act(x.B, x.H, x.W, w.cout);
+    AF_TRY(R.conv(w.skip, x, sk, 1, 0, nullptr, nullptr, 0));
+  }
+  AF_TRY(R.conv(w.c2, t3, out, 1, 0, &sk, nullptr, 0));
+  R.A.release(mk);
+  return 0;
+}
+
+// SpatialTransformer.forward (attention.py:321-341) incl. BasicTransformerBlock (:275-285)
+static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out) {
+  af_handle* h = R.h;
+  const size_t mk = R.A.mark();
+  const int B = x.B, H = x.H, W = x.W, N = H * W, C = w.heads * w.dh;
+  Act g = R.alloc_act(B, H, W, x.C);
+  AF_TRY(R.groupnorm(w.gn, x, g, 0));
+  Act t = R.alloc_act(B, H, W, C);
+  AF_TRY(R.conv(w.proj_in, g, t, 1, 0, nullptr, nullptr, 0));
+  for (size_t d = 0; d < w.blocks.size(); ++d) {
+    const XfmrBlockW& blk = w.blocks[d];
+    const size_t mk2 = R.A.mark();
+    // --- x = attn1(norm1(x)) + x ---
+    Act n = R.alloc_act(B, H, W, C);
+    AF_TRY(R.layernorm(blk.ln1, t, n));
+    Act qkv = R.alloc_act(B, H, W, 3 * C);
+    AF_TRY(R.conv(blk.qkv1, n, qkv, 1, 0, nullptr, nullptr, 0));
+    Act a = R.alloc_act(B, H, W, C);
+    AF_TRY(R.attention(qkv.p, 3 * C, (long)N * 3 * C, R.elem_ptr(qkv.p, C), 3 * C, (long)N * 3 * C,
+                       R.elem_ptr(qkv.p, 2 * C), 3 * C, (long)N * 3 * C, a, N, N, w.heads, w.dh));
+    Act t1 = R.alloc_act(B, H, W, C);
+    AF_TRY(R.conv(blk.out1, a, t1, 1, 0, &t, nullptr, 0));
+    // --- x = x + attn2(norm2(x), context) ---
+    AF_TRY(R.layernorm(blk.ln2, t1, n));
+    Act q = R.alloc_act(B, H, W, C);
+    AF_TRY(R.conv(blk.q2, n, q, 1, 0, nullptr, nullptr, 0));
+    const CtxKV& kv = h->ctx_kv[w.ca_slot + d];
+    const int S = h->ctx_tokens;
+    if (!R.dry && (!kv.kv || h->ctx_Bf != B)) {
+      af_set_error_msg("context not set for batch %d (af_set_context)", B);
+      return AF_ERR_STATE;
+    }
+    AF_TRY(R.attention(q.p, C, (long)N * C, kv.kv, 2 * C, (long)S * 2 * C, R.dry ? nullptr : R.elem_ptr(kv.kv, C),
+                       2 * C, (long)S * 2 * C, a, N, S, w.heads, w.dh));
+    Act t2 = R.alloc_act(B, H, W, C);
+    AF_TRY(R.conv(blk.out2, a, t2, 1, 0, &t1, nullptr, 0));
+    // --- x = ff(norm3(x)) + x ---
+    AF_TRY(R.layernorm(blk.ln3, t2, n));
+    Act f = R.alloc_act(B, H, W, 4 * C);
+    AF_TRY(R.conv(blk.ff1, n, f, 1, 0, nullptr, nullptr, 0, 8 * C));
+    // write the block output over `t` (its last reader was out1's residual)
+    AF_TRY(R.conv(blk.ff2, f, t, 1, 0, &t2, nullptr, 0));
+    R.A.release(mk2);
+  }
+  AF_TRY(R.conv(w.proj_out, t, out, 1, 0, &x, nullptr, 0));
+  R.A.release(mk);
+  return 0;
+}
+
+static int ensure_arena(af_handle* h, size_t need) {
+  if (need <= h->arena.cap) return 0;
+  if (h->arena.base) hipFree(h->arena.base);
+  h->arena.base = nullptr;
+  h->arena.cap = 0;
+  need += need / 16;
+  void* p = nullptr;
+  if (hipMalloc(&p, need) != hipSuccess) {
+    af_set_error_msg("hipMalloc of %zu-byte activation arena failed", need);
+    return AF_ERR_HIP;
+  }
+  h->arena.base = reinterpret_cast<char*>(p);
+  h->arena.cap = need;
+  return 0;
+}
+
+// UNetModel.forward (openaimodel.py:827-1052)
+static int unet_forward_impl(af_handle* h, hipStream_t s, const float* x_dev, const int64_t* t_dev, float* eps_dev,
+                             int Bf, int H, int W) {
+  Runner R(h, s);
+  const af_config& c = h->cfg;
+  const int dt = h->dtype;
+  const int mc = c.model_channels, ted = 4 * mc;
+  R.A.off = 0;
+
+  // x -> NHWC with channels zero-padded to the first conv's K tile
+  Act x = R.alloc_act(Bf, H, W, c.in_channels, h->conv_in.cin_pad);
+  AF_TRY(R.check(x));
+  // time embedding: timestep_embedding -> Linear -> SiLU -> Linear (openaimodel.py:846-847), then the
+  // SiLU that opens every emb_layers (openaimodel.py:222-228) and the fused emb_layers.1 linears
+  Act temb = R.alloc_act(Bf, 1, 1, mc);
+  Act e1 = R.alloc_act(Bf, 1, 1, ted);
+  Act e2 = R.alloc_act(Bf, 1, 1, ted);
+  Act emb_all = R.alloc_act(Bf, 1, 1, h->emb_total);
+  AF_TRY(R.check(emb_all));
+  if (!R.dry) {
+    AF_TRY(DISPATCH(dt, af_launch_nchw_to_nhwc<bf16>(x_dev, x.p, Bf, c.in_channels, H * W, x.ld, 1.0f, s),
+                    af_launch_nchw_to_nhwc<float>(x_dev, x.p, Bf, c.in_channels, H * W, x.ld, 1.0f, s)));
+    AF_TRY(DISPATCH(dt, af_launch_timestep_embedding<bf16>((const long long*)t_dev, temb.p, Bf, mc, s),
+                    af_launch_timestep_embedding<float>((const long long*)t_dev, temb.p, Bf, mc, s)));
+  }
+  AF_TRY(R.conv(h->time_embed0, temb, e1, 1, 0, nullptr, nullptr, 0));
+  if (!R.dry) AF_TRY(DISPATCH(dt, af_launch_silu<bf16>(e1.p, e1.p, (long)Bf * ted, s), af_launch_silu<float>(e1.p, e1.p, (long)Bf * ted, s)));
+  AF_TRY(R.conv(h->time_embed2, e1, e2, 1, 0, nullptr, nullptr, 0));
+  if (!R.dry) AF_TRY(DISPATCH(dt, af_launch_silu<bf16>(e2.p, e2.p, (long)Bf * ted, s), af_launch_silu<float>(e2.p, e2.p, (long)Bf * ted, s)));
+  AF_TRY(R.conv(h->emb_all, e2, emb_all, 1, 0, nullptr, nullptr, 0));
+
+  auto run_block = [&](const UBlock& ub, Act hcur, Act& result) -> int {
+    for (auto& l : ub.layers) {
+      Act out;
+      switch (l.kind) {
+        case L_CONV_IN: {
+          out = R.alloc_act(Bf, hcur.H, hcur.W, mc);
+          Act xin = hcur;
+          xin.C = h->conv_in.cin;  // logical channels; ld carries the padding
+          AF_TRY(R.conv(h->conv_in, xin, out, 1, 0, nullptr, nullptr, 0));
+        } break;
+        case L_RES: {
+          const ResBlockW& w = h->res[l.idx];
+          out = R.alloc_act(Bf, hcur.H, hcur.W, w.cout);
+          AF_TRY(run_resblock(R, w, hcur, out, emb_all.p, emb_all.ld));
+        } break;
+        case L_XFMR: {
+          out = R.alloc_act(Bf, hcur.H, hcur.W, hcur.C);
+          AF_TRY(run_xfmr(R, h->xf[l.idx], hcur, out));
+        } break;
+        case L_DOWN: {
+          out = R.alloc_act(Bf, hcur.H / 2, hcur.W / 2, hcur.C);
+          AF_TRY(R.conv(h->updown[l.idx], hcur, out, 2, 0, nullptr, nullptr, 0));
+        } break;
+        case L_UP: {
+          out = R.alloc_act(Bf, hcur.H * 2, hcur.W * 2, hcur.C);
+          AF_TRY(R.conv(h->updown[l.idx], hcur, out, 1, 1, nullptr, nullptr, 0));
+        } break;
+      }
+      hcur = out;
+    }
+    result = hcur;
+    return 0;
+  };
+
+  std::vector<Act> hs;
+  Act hcur = x;
+  for (auto& ub : h->input_blocks) {
+    Act o;
+    AF_TRY(run_block(ub, hcur, o));
+    hcur = o;
+    hs.push_back(hcur);
+  }
+  {
+    Act o;
+    AF_TRY(run_block(h->middle_block, hcur, o));
+    hcur = o;
+  }
+  for (auto& ub : h->output_blocks) {
+    Act skip = hs.back();
+    hs.pop_back();
+    // h = cat([h, hs.pop()], dim=1)  (openaimodel.py:1018-1019)
+    Act cat = R.alloc_act(Bf, hcur.H, hcur.W, hcur.C + skip.C);
+    AF_TRY(R.check(cat));
+    AF_TRY(R.copy_channels(hcur, cat, 0));
+    AF_TRY(R.copy_channels(skip, cat, hcur.C));
+    Act o;
+    AF_TRY(run_block(ub, cat, o));
+    hcur = o;
+  }
+  // out: GroupNorm32 -> SiLU -> conv3x3 (openaimodel.py:693-697)
+  Act g = R.alloc_act(Bf, hcur.H, hcur.W, hcur.C);
+  AF_TRY(R.groupnorm(h->out_norm, hcur, g, 1));
+  const int oc4 = round_up(c.out_channels, 4);
+  Act e = R.alloc_act(Bf, hcur.H, hcur.W, c.out_channels, oc4);
+  AF_TRY(R.conv(h->out_conv, g, e, 1, 0, nullptr, nullptr, 0));
+  if (!R.dry)
+    AF_TRY(DISPATCH(dt, af_launch_nhwc_to_nchw<bf16>(e.p, eps_dev, Bf, c.out_channels, H * W, e.ld, s),
+                    af_launch_nhwc_to_nchw<float>(e.p, eps_dev, Bf, c.out_channels, H * W, e.ld, s)));
+  return 0;
+}
+
+// AttnBlock.forward (model.py:179-242): single head over C channels, N = H*W tokens
+static int run_vae_attn(Runner& R, const VaeAttnW& w, const Act& x, Act& out) {
+  const size_t mk = R.A.mark();
+  const int B = x.B, N = x.H * x.W, C = w.C, dt = R.dt;
+  Act g = R.alloc_act(B, x.H, x.W, C);
+  AF_TRY(R.groupnorm(w.gn, x, g, 0));
+  Act qkv = R.alloc_act(B, x.H, x.W, 3 * C);
+  AF_TRY(R.conv(w.qkv, g, qkv, 1, 0, nullptr, nullptr, 0));
+  Act sc = R.alloc_act(B, N, 1, N);       // scores [B][N][N]
+  Act vt = R.alloc_act(B, C, 1, N);       // v^T   [B][C][N]
+  Act hh = R.alloc_act(B, x.H, x.W, C);
+  AF_TRY(R.check(hh));
+  if (!R.dry) {
+    ConvGemmParams p;
+    memset(&p, 0, sizeof(p));
+    // scores[b][i][j] = C^-0.5 * sum_c q[b][i][c] k[b][j][c]
+    p.src = qkv.p; p.src_batch_stride = 0; p.ldc = 3 * C; p.Cin = C;
+    p.Hs = 1; p.Ws = N; p.Hi = 1; p.Wi = N; p.Ho = 1; p.Wo = N; p.ks = 1; p.stride = 1; p.pad = 0;
+    p.W = R.elem_ptr(qkv.p, C); p.ldw = 3 * C; p.Wrows = N;
+    p.M = N; p.N = N; p.K = C;
+    p.out = sc.p; p.ldo = N; p.alpha = 1.0f / sqrtf((float)C);
+    p.bs_src = (long)N * 3 * C; p.bs_w = (long)N * 3 * C; p.bs_out = (long)N * N;
+    AF_TRY(R.gemm_raw(p, B));
+    AF_TRY(DISPATCH(dt, af_launch_softmax_rows<bf16>(sc.p, N, N, (long)B * N, R.s),
+                    af_launch_softmax_rows<float>(sc.p, N, N, (long)B * N, R.s)));
+    AF_TRY(DISPATCH(dt, af_launch_transpose<bf16>(R.elem_ptr(qkv.p, 2 * C), (long)N * 3 * C, 3 * C, vt.p, (long)C * N, N, C, B, R.s),
+                    af_launch_transpose<float>(R.elem_ptr(qkv.p, 2 * C), (long)N * 3 * C, 3 * C, vt.p, (long)C * N, N, C, B, R.s)));
+    // h[b][i][c] = sum_j P[b][i][j] v[b][j][c]
+    memset(&p, 0, sizeof(p));
+    p.src = sc.p; p.src_batch_stride = 0; p.ldc = N; p.Cin = N;
+    p.Hs = 1; p.Ws = N; p.Hi = 1; p.Wi = N; p.Ho = 1; p.Wo = N; p.ks = 1; p.stride = 1; p.pad = 0;
+    p.W = vt.p; p.ldw = N; p.Wrows = C;
+    p.M = N; p.N = C; p.K = N;
+    p.out = hh.p; p.ldo = C; p.alpha = 1.0f;
+    p.bs_src = (long)N * N; p.bs_w = (long)C * N; p.bs_out = (long)N * C;
+    AF_TRY(R.gemm_raw(p, B));
+  }
+  AF_TRY(R.conv(w.proj_out, hh, out, 1, 0, &x, nullptr, 0));
+  R.A.release(mk);
+  return 0;
+}
+
+// decode_first_stage + AutoencoderKL.decode + Decoder.forward
+static int vae_decode_impl(af_handle* h, hipStream_t s, const float* z_dev, float scale_factor, float* img_dev,
+                           uint8_t* u8_dev, int B, int H, int W) {
+  Runner R(h, s);
+  const af_config& c = h->cfg;
+  const int dt = h->dtype;
+  R.A.off = 0;
+  Act z = R.alloc_act(B, H, W, c.vae_embed_dim, h->post_quant.cin_pad);
+  Act z2 = R.alloc_act(B, H, W, c.vae_z_channels, h->vae_conv_in.cin_pad);
+  AF_TRY(R.check(z2));
+  if (!R.dry) {
+    AF_TRY(DISPATCH(dt, af_launch_nchw_to_nhwc<bf16>(z_dev, z.p, B, c.vae_embed_dim, H * W, z.ld, 1.0f / scale_factor, s),
+                    af_launch_nchw_to_nhwc<float>(z_dev, z.p, B, c.vae_embed_dim, H * W, z.ld, 1.0f / scale_factor, s)));
+    HIP_CHECK_RET(hipMemsetAsync(z2.p, 0, (size_t)z2.npix() * z2.ld * esize(dt), s));
+  }
+  AF_TRY(R.conv(h->post_quant, z, z2, 1, 0, nullptr, nullptr, 0));
+  Act hcur = R.alloc_act(B, H, W, h->vae_conv_in.cout);
+  AF_TRY(R.conv(h->vae_conv_in, z2, hcur, 1, 0, nullptr, nullptr, 0));
+  auto res = [&](int ri) -> int {
+    const ResBlockW& w = h->vres[ri];
+    Act out = R.alloc_act(B, hcur.H, hcur.W, w.cout);
+    AF_TRY(run_resblock(R, w, hcur, out, nullptr, 0));
+    hcur = out;
+    return 0;
+  };
+  AF_TRY(res(h->vmid1));
+  {
+    Act out = R.alloc_act(B, hcur.H, hcur.W, hcur.C);
+    AF_TRY(run_vae_attn(R, h->vattn, hcur, out));
+    hcur = out;
+  }
+  AF_TRY(res(h->vmid2));
+  for (int lvl = (int)h->vlevels.size() - 1; lvl >= 0; --lvl) {
+    // free everything below the level input once the level is done is not needed: the arena is sized
+    // for the whole decode; per-block temporaries are released inside run_resblock.
+    for (int ri : h->vlevels[lvl].blocks) AF_TRY(res(ri));
+    if (h->vlevels[lvl].up >= 0) {
+      Act out = R.alloc_act(B, hcur.H * 2, hcur.W * 2, hcur.C);
+      AF_TRY(R.conv(h->vup[h->vlevels[lvl].up], hcur, out, 1, 1, nullptr, nullptr, 0));
+      hcur = out;
+    }
+  }
+  Act g = R.alloc_act(B, hcur.H, hcur.W, hcur.C);
+  AF_TRY(R.groupnorm(h->vae_norm_out, hcur, g, 1));
+  const int oc4 = round_up(c.vae_out_ch, 4);
+  Act img = R.alloc_act(B, hcur.H, hcur.W, c.vae_out_ch, oc4);
+  AF_TRY(R.conv(h->vae_conv_out, g, img, 1, 0, nullptr, nullptr, 0));
+  if (!R.dry) {
+    if (img_dev)
+      AF_TRY(DISPATCH(dt, af_launch_nhwc_to_nchw<bf16>(img.p, img_dev, B, c.vae_out_ch, img.H * img.W, img.ld, s),
+                      af_launch_nhwc_to_nchw<float>(img.p, img_dev, B, c.vae_out_ch, img.H * img.W, img.ld, s)));
+    if (u8_dev) {
+      if (c.vae_out_ch != 3) { af_set_error_msg("uint8 output needs out_ch == 3"); return AF_ERR_INVALID; }
+      AF_TRY(DISPATCH(dt, af_launch_to_uint8<bf16>(img.p, img.ld, u8_dev, img.npix(), s),
+                      af_launch_to_uint8<float>(img.p, img.ld, u8_dev, img.npix(), s)));
+    }
+  }
+  return 0;
+}
+
+// ============================================================================
+// C ABI
+// ============================================================================
+extern "C" {
+
+const char* af_last_error(void) { return g_err; }
+int af_version(void) { return 1; }
+
+int af_create(int device_id, const af_config* cfg, af_handle** out) {
+  if (!cfg || !out) { af_set_error_msg("af_create: null argument"); return AF_ERR_INVALID; }
+  if (cfg->dtype != AF_DTYPE_BF16 && cfg->dtype != AF_DTYPE_F32) { af_set_error_msg("af_create: bad dtype"); return AF_ERR_INVALID; }
+  HIP_CHECK_RET(hipSetDevice(device_id));
+  std::unique_ptr<af_handle> h(new af_handle());
+  h->device = device_id;
+  h->cfg = *cfg;
+  h->dtype = cfg->dtype;
+  Builder b{h.get()};
+  if (cfg->build_unet) {
+    if (cfg->n_channel_mult <= 0 || cfg->n_channel_mult > 8 || cfg->n_attention_resolutions > 8) {
+      af_set_error_msg("af_create: bad channel_mult / attention_resolutions");
+      return AF_ERR_INVALID;
+    }
+    int rc = build_unet(b);
+    if (rc) { af_destroy(h.release()); return rc; }
+  }
+  if (cfg->build_vae) {
+    if (cfg->n_vae_ch_mult <= 0 || cfg->n_vae_ch_mult > 8) { af_set_error_msg("af_create: bad vae_ch_mult"); return AF_ERR_INVALID; }
+    int rc = build_vae(b);
+    if (rc) { af_destroy(h.release()); return rc; }
+  }
+  if (b.rc) { af_destroy(h.release()); return b.rc; }
+  HIP_CHECK_RET(hipDeviceSynchronize());
+  *out = h.release();
+  return 0;
+}
+
+void af_destroy(af_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipDeviceSynchronize();
+  for (void* p : h->owned) hipFree(p);
+  for (auto& kv : h->ctx_kv) if (kv.kv) hipFree(kv.kv);
+  if (h->ctx_cast) hipFree(h->ctx_cast);
+  if (h->arena.base) hipFree(h->arena.base);
+  if (h->stage) hipFree(h->stage);
+  delete h;
+}
+
+int af_num_tensors(af_handle* h) { return h ? (int)h->slot_names.size() : 0; }
+const char* af_tensor_name(af_handle* h, int i) {
+  if (!h || i < 0 || i >= (int)h->slot_names.size()) return nullptr;
+  return h->slot_names[i].c_str();
+}
+int af_tensor_loaded(af_handle* h, int i) {
+  if (!h || i < 0 || i >= (int)h->slot_names.size()) return 0;
+  return h->slots[h->slot_names[i]].loaded ? 1 : 0;
+}
+int af_tensor_shape(af_handle* h, int i, int64_t* shape4) {
+  if (!h || i < 0 || i >= (int)h->slot_names.size()) return AF_ERR_INVALID;
+  const Slot& s = h->slots[h->slot_names[i]];
+  for (int d = 0; d < 4; ++d) shape4[d] = d < (int)s.shape.size() ? s.shape[d] : 0;
+  return (int)s.shape.size();
+}
+
+int af_load_tensor(af_handle* h, const char* name, const float* host_data, int ndim, const int64_t* shape) {
+  if (!h || !name || !host_data) { af_set_error_msg("af_load_tensor: null argument"); return AF_ERR_INVALID; }
+  auto it = h->slots.find(name);
+  if (it == h->slots.end()) { af_set_error_msg("af_load_tensor: unknown tensor '%s'", name); return AF_ERR_NAME; }
+  Slot& s = it->second;
+  int64_t n = 1, nexp = 1;
+  for (int d = 0; d < ndim; ++d) n *= shape[d];
+  for (auto v : s.shape) nexp *= v;
+  // accept [out,in] for a 1x1 conv slot and vice versa (same element count and leading dims)
+  bool ok = n == nexp && ndim >= 1 && shape[0] == s.shape[0];
+  if (ok && s.shape.size() >= 2 && ndim >= 2) ok = shape[1] == s.shape[1];
+  if (!ok) {
+    af_set_error_msg("af_load_tensor: shape mismatch for '%s' (got %lld elements, dim0 %lld; expected %lld, dim0 %lld)",
+                     name, (long long)n, (long long)shape[0], (long long)nexp, (long long)s.shape[0]);
+    return AF_ERR_INVALID;
+  }
+  HIP_CHECK_RET(hipSetDevice(h->device));
+  const size_t bytes = (size_t)n * sizeof(float);
+  if (bytes > h->stage_bytes) {
+    if (h->stage) hipFree(h->stage);
+    h->stage = nullptr;
+    h->stage_bytes = 0;
+    void* p = nullptr;
+    HIP_CHECK_RET(hipMalloc(&p, bytes));
+    h->stage = reinterpret_cast<float*>(p);
+    h->stage_bytes = bytes;
+  }
+  HIP_CHECK_RET(hipMemcpy(h->stage, host_data, bytes, hipMemcpyHostToDevice));
+  if (s.kind == Slot::WEIGHT) {
+    AF_TRY(DISPATCH(h->dtype,
+                    af_launch_repack_weight<bf16>(h->stage, s.dst, s.rows, s.cin, s.cin_pad, s.ks, s.ldw, s.row_off, s.perm, 0),
+                    af_launch_repack_weight<float>(h->stage, s.dst, s.rows, s.cin, s.cin_pad, s.ks, s.ldw, s.row_off, s.perm, 0)));
+  } else {
+    AF_TRY(af_launch_permute_bias(h->stage, s.dst_f, s.rows, s.perm, 0));
+  }
+  HIP_CHECK_RET(hipStreamSynchronize(0));
+  s.loaded = true;
+  return 0;
+}
+
+static int check_loaded(af_handle* h, const char* prefix) {
+  for (auto& kv : h->slots)
+    if (!kv.second.loaded && kv.first.compare(0, strlen(prefix), prefix) == 0) {
+      af_set_error_msg("tensor '%s' has not been loaded (af_load_tensor)", kv.first.c_str());
+      return AF_ERR_STATE;
+    }
+  return 0;
+}
+
+int af_set_context(af_handle* h, const float* ctx_dev, int Bf, int n_tokens, int layerwise, void* stream) {
+  if (!h || !ctx_dev || Bf <= 0 || n_tokens <= 0) { af_set_error_msg("af_set_context: bad argument"); return AF_ERR_INVALID; }
+  if (!h->cfg.build_unet) { af_set_error_msg("af_set_context: handle has no UNet"); return AF_ERR_STATE; }
+  HIP_CHECK_RET(hipSetDevice(h->device));
+  AF_TRY(check_loaded(h, "model.diffusion_model."));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int dt = h->dtype, D = h->cfg.context_dim;
+  const int L = layerwise ? h->cfg.n_context_layers : 1;
+  if (layerwise && (int)h->ca_list.size() > L * h->cfg.transformer_depth) {
+    af_set_error_msg("af_set_context: %zu cross-attention layers but only %d context layers", h->ca_list.size(), L);
+    return AF_ERR_INVALID;
+  }
+  const size_t n = (size_t)Bf * L * n_tokens * D;
+  if (n * esize(dt) > h->ctx_cast_bytes || h->ctx_Bf != Bf || h->ctx_tokens != n_tokens) {
+    HIP_CHECK_RET(hipStreamSynchronize(s));
+    if (h->ctx_cast) hipFree(h->ctx_cast);
+    h->ctx_cast = nullptr;
+    HIP_CHECK_RET(hipMalloc(&h->ctx_cast, n * esize(dt)));
+    h->ctx_cast_bytes = n * esize(dt);
+    for (size_t i = 0; i < h->ctx_kv.size(); ++i) {
+      if (h->ctx_kv[i].kv) hipFree(h->ctx_kv[i].kv);
+      const XfmrW& x = h->xf[h->ca_list[i].first];
+      const int C = x.heads * x.dh;
+      h->ctx_kv[i].C = C;
+      h->ctx_kv[i].kv = nullptr;
+      HIP_CHECK_RET(hipMalloc(&h->ctx_kv[i].kv, (size_t)Bf * n_tokens * 2 * C * esize(dt)));
+    }
+  }
+  AF_TRY(DISPATCH(dt, af_launch_cast_f32<bf16>(ctx_dev, h->ctx_cast, (long)n, s), af_launch_cast_f32<float>(ctx_dev, h->ctx_cast, (long)n, s)));
+  for (size_t i = 0; i < h->ca_list.size(); ++i) {
+    const XfmrW& x = h->xf[h->ca_list[i].first];
+    const XfmrBlockW& blk = x.blocks[h->ca_list[i].second];
+    const int C = x.heads * x.dh;
+    // context.reshape(B,16,T,D).permute(1,0,2,3)[layer] (openaimodel.py:866,883): sample b, layer l sits at
+    // row block (b*L + l) of ctx.  The layer index follows the TRANSFORMER (ca layer), not the depth.
+    const int layer = layerwise ? x.ca_slot / (int)x.blocks.size() : 0;
+    ConvGemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.src = reinterpret_cast<char*>(h->ctx_cast) + (size_t)layer * n_tokens * D * esize(dt);
+    p.src_batch_stride = (long)L * n_tokens * D;
+    p.ldc = D; p.Cin = D;
+    p.Hs = 1; p.Ws = n_tokens; p.Hi = 1; p.Wi = n_tokens; p.Ho = 1; p.Wo = n_tokens;
+    p.ks = 1; p.stride = 1; p.pad = 0;
+    p.W = blk.kv2.w; p.ldw = blk.kv2.ldw; p.Wrows = blk.kv2.rows_pad;
+    p.M = Bf * n_tokens; p.N = 2 * C; p.K = D;
+    p.out = h->ctx_kv[i].kv; p.ldo = 2 * C; p.alpha = 1.0f;
+    AF_TRY(DISPATCH(dt, af_launch_conv_gemm<bf16>(p, 1, s), af_launch_conv_gemm<float>(p, 1, s)));
+  }
+  h->ctx_Bf = Bf;
+  h->ctx_tokens = n_tokens;
+  h->ctx_set = true;
+  return 0;
+}
+
+int af_unet_forward(af_handle* h, const float* x_dev, const int64_t* t_dev, float* eps_dev, int Bf, int H, int W,
+                    void* stream) {
+  if (!h || !x_dev || !t_dev || !eps_dev) { af_set_error_msg("af_unet_forward: null argument"); return AF_ERR_INVALID; }
+  if (!h->cfg.build_unet) { af_set_error_msg("af_unet_forward: handle has no UNet"); return AF_ERR_STATE; }
+  if (!h->ctx_set || h->ctx_Bf != Bf) { af_set_error_msg("af_unet_forward: call af_set_context for batch %d first", Bf); return AF_ERR_STATE; }
+  const int down = 1 << (h->cfg.n_channel_mult - 1);
+  if (H % down || W % down) { af_set_error_msg("af_unet_forward: H,W must be multiples of %d", down); return AF_ERR_INVALID; }
+  HIP_CHECK_RET(hipSetDevice(h->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // size the arena with a dry run
+  h->arena.dry = true; h->arena.peak = 0;
+  int rc = unet_forward_impl(h, s, x_dev, t_dev, eps_dev, Bf, H, W);
+  h->arena.dry = false;
+  if (rc) return rc;
+  if (h->arena.peak > h->arena.cap) { HIP_CHECK_RET(hipStreamSynchronize(s)); AF_TRY(ensure_arena(h, h->arena.peak)); }
+  return unet_forward_impl(h, s, x_dev, t_dev, eps_dev, Bf, H, W);
+}
+
+int af_ddim_step(const float* x_dev, const float* eps_cond_dev, const float* eps_uncond_dev, const float* noise_dev,
+                 int64_t n, float guidance, float a_t, float a_prev, float sqrt_one_minus_at, float sigma_t,
+                 float temperature, float* x_prev_dev, float* pred_x0_dev, void* stream) {
+  if (!x_dev || !eps_cond_dev || !x_prev_dev || n <= 0) { af_set_error_msg("af_ddim_step: bad argument"); return AF_ERR_INVALID; }
+  return af_launch_ddim_step(x_dev, eps_cond_dev, eps_uncond_dev, noise_dev, (long)n, guidance, a_t, a_prev,
+                             sqrt_one_minus_at, sigma_t, temperature, x_prev_dev, pred_x0_dev,
+                             reinterpret_cast<hipStream_t>(stream));
+}
+
+int af_vae_decode(af_handle* h, const float* z_dev, float scale_factor, float* img_dev, uint8_t* u8_dev, int B, int H,
+                  int W, void* stream) {
+  if (!h || !z_dev || (!img_dev && !u8_dev)) { af_set_error_msg("af_vae_decode: null argument"); return AF_ERR_INVALID; }
+  if (!h->cfg.build_vae) { af_set_error_msg("af_vae_decode: handle has no VAE"); return AF_ERR_STATE; }
+  HIP_CHECK_RET(hipSetDevice(h->device));
+  AF_TRY(check_loaded(h, "first_stage_model."));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  h->arena.dry = true; h->arena.peak = 0;
+  int rc = vae_decode_impl(h, s, z_dev, scale_factor, img_dev, u8_dev, B, H, W);
+  h->arena.dry = false;
+  if (rc) return rc;
+  if (h->arena.peak > h->arena.cap) { HIP_CHECK_RET(hipStreamSynchronize(s)); AF_TRY(ensure_arena(h, h->arena.peak)); }
+  return vae_decode_impl(h, s, z_dev, scale_factor, img_dev, u8_dev, B, H, W);
+}
+
+int af_to_uint8(const float* img_dev, uint8_t* u8_dev, int B, int H, int W, void* stream) {
+  if (!img_dev || !u8_dev) { af_set_error_msg("af_to_uint8: null argument"); return AF_ERR_INVALID; }
+  return af_launch_nchw_to_uint8(img_dev, u8_dev, B, H * W, reinterpret_cast<hipStream_t>(stream));
+}
+
+int64_t af_arena_bytes(af_handle* h) { return h ? (int64_t)h->arena.cap : 0; }
+
+}  // extern "C"

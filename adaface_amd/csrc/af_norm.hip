@@ -1,0 +1,286 @@
+// GroupNorm(32)(+SiLU) and LayerNorm kernels for gfx950, NHWC activations.
+//
+// Replaces GroupNorm32 / normalization (ldm/modules/diffusionmodules/util.py:202-219,
+// eps 1e-5, fp32 math), Normalize (attention.py:71-72 and model.py:39-40, eps 1e-6),
+// the nn.SiLU / nonlinearity that always follows them in ResBlock / ResnetBlock
+// (openaimodel.py:205-207,229-231; model.py:34-36) and nn.LayerNorm
+// (attention.py:267-269).  All are HBM-bound: every access is a 16-byte vector,
+// pixel-major so a wave reads contiguous memory; statistics are fp32 partial sums
+// combined in fp64 (biased variance, as torch).
+//
+//   gn_stats    grid (chunks, B): per-(sample, pixel-chunk, group) sum / sumsq
+//   gn_finalize grid (B)        : fp64 combine -> mean, rstd per (sample, group)
+//   gn_apply    grid (chunks, B): y = (x-mean)*rstd*gamma+beta, optional SiLU
+//   layernorm   one wave per row, row held in registers, two-pass variance
+#include "af_common.h"
+
+#define GN_GROUPS 32
+#define GN_MAX_C 2560
+
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, long batch_stride, int ldc,
+                                                        int HW, int Cn, int P, float* __restrict__ partial,
+                                                        int nchunk) {
+  constexpr int EPC = 16 / sizeof(T);
+  __shared__ float s_sum[GN_MAX_C];
+  __shared__ float s_sq[GN_MAX_C];
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int NV = Cn / EPC;  // 16-byte vectors per pixel
+  for (int c = tid; c < Cn; c += 256) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
+  __syncthreads();
+
+  const int p0 = chunk * P;
+  const int p1 = min(HW, p0 + P);
+  const T* xb = x + (long)b * batch_stride;
+
+  if (NV <= 256) {
+    const int PL = 256 / NV;  // pixel lanes
+    const int v = tid % NV, pl = tid / NV;
+    if (pl < PL) {
+      float a[EPC], q[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { a[e] = 0.f; q[e] = 0.f; }
+      for (int pix = p0 + pl; pix < p1; pix += PL) {
+        Vec16<T> vv;
+        vv.u = *reinterpret_cast<const uint4*>(xb + (long)pix * ldc + v * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          float f = to_f32<T>(vv.e[e]);
+          a[e] += f;
+          q[e] += f * f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        atomicAdd(&s_sum[v * EPC + e], a[e]);
+        atomicAdd(&s_sq[v * EPC + e], q[e]);
+      }
+    }
+  } else {
+    for (int v = tid; v < NV; v += 256) {
+      float a[EPC], q[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { a[e] = 0.f; q[e] = 0.f; }
+      for (int pix = p0; pix < p1; ++pix) {
+        Vec16<T> vv;
+        vv.u = *reinterpret_cast<const uint4*>(xb + (long)pix * ldc + v * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          float f = to_f32<T>(vv.e[e]);
+          a[e] += f;
+          q[e] += f * f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        s_sum[v * EPC + e] = a[e];
+        s_sq[v * EPC + e] = q[e];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < GN_GROUPS) {
+    const int cpg = Cn / GN_GROUPS;
+    float a = 0.f, q = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += s_sum[c]; q += s_sq[c]; }
+    float* dst = partial + (((long)b * nchunk + chunk) * GN_GROUPS + tid) * 2;
+    dst[0] = a;
+    dst[1] = q;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nchunk,
+                                                           double count, float eps,
+                                                           float* __restrict__ stats) {
+  // 256 threads = 32 groups x 8 slices over the chunks
+  __shared__ double s_a[256], s_q[256];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int g = tid & 31, sl = tid >> 5;
+  double a = 0.0, q = 0.0;
+  for (int c = sl; c < nchunk; c += 8) {
+    const float* src = partial + (((long)b * nchunk + c) * GN_GROUPS + g) * 2;
+    a += (double)src[0];
+    q += (double)src[1];
+  }
+  s_a[tid] = a;
+  s_q[tid] = q;
+  __syncthreads();
+  if (tid < 32) {
+    for (int s = 1; s < 8; ++s) { a += s_a[tid + 32 * s]; q += s_q[tid + 32 * s]; }
+    double mean = a / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[((long)b * GN_GROUPS + tid) * 2 + 0] = (float)mean;
+    stats[((long)b * GN_GROUPS + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long batch_stride, int ldc,
+                                                        int HW, int Cn, int P,
+                                                        const float* __restrict__ stats,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int silu,
+                                                        T* __restrict__ y, long y_batch_stride, int ldy) {
+  constexpr int EPC = 16 / sizeof(T);
+  __shared__ float s_a[GN_MAX_C];
+  __shared__ float s_b[GN_MAX_C];
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int cpg = Cn / GN_GROUPS;
+  for (int c = tid; c < Cn; c += 256) {
+    const int g = c / cpg;
+    const float mean = stats[((long)b * GN_GROUPS + g) * 2 + 0];
+    const float rstd = stats[((long)b * GN_GROUPS + g) * 2 + 1];
+    const float a = gamma[c] * rstd;
+    s_a[c] = a;
+    s_b[c] = beta[c] - mean * a;
+  }
+  __syncthreads();
+  const int NV = Cn / EPC;
+  const int p0 = chunk * P;
+  const int p1 = min(HW, p0 + P);
+  const int nitems = (p1 - p0) * NV;
+  const T* xb = x + (long)b * batch_stride;
+  T* yb = y + (long)b * y_batch_stride;
+  for (int it = tid; it < nitems; it += 256) {
+    const int pix = p0 + it / NV;
+    const int v = it % NV;
+    Vec16<T> vv, oo;
+    vv.u = *reinterpret_cast<const uint4*>(xb + (long)pix * ldc + v * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int c = v * EPC + e;
+      float f = to_f32<T>(vv.e[e]) * s_a[c] + s_b[c];
+      if (silu) f = silu_f(f);
+      oo.e[e] = from_f32<T>(f);
+    }
+    *reinterpret_cast<uint4*>(yb + (long)pix * ldy + v * EPC) = oo.u;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm: one wave per row; C*sizeof(T)/16 <= 64*LN_MAXV vectors.
+// ---------------------------------------------------------------------------
+#define LN_MAXV 5
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int ldx, long rows, int Cn,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps,
+                                                         T* __restrict__ y, int ldy) {
+  constexpr int EPC = 16 / sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int NV = Cn / EPC;
+  Vec16<T> v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < NV) {
+      v[i].u = *reinterpret_cast<const uint4*>(x + row * ldx + vi * EPC);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) s += to_f32<T>(v[i].e[e]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)Cn;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < NV) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const float d = to_f32<T>(v[i].e[e]) - mean;
+        q += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q / (float)Cn + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < NV) {
+      Vec16<T> o;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const int c = vi * EPC + e;
+        o.e[e] = from_f32<T>((to_f32<T>(v[i].e[e]) - mean) * rstd * gamma[c] + beta[c]);
+      }
+      *reinterpret_cast<uint4*>(y + row * ldy + vi * EPC) = o.u;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------
+int af_gn_chunking(int HW, int* P_out) {
+  int P = 64;
+  while ((HW + P - 1) / P > 256) P *= 2;
+  *P_out = P;
+  return (HW + P - 1) / P;
+}
+
+// workspace: partial [B][nchunk][32][2] floats + stats [B][32][2] floats
+size_t af_gn_workspace_bytes(int B, int HW) {
+  int P;
+  int nchunk = af_gn_chunking(HW, &P);
+  return ((size_t)B * nchunk * GN_GROUPS * 2 + (size_t)B * GN_GROUPS * 2) * sizeof(float);
+}
+
+template <typename T>
+int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn, const float* gamma,
+                        const float* beta, float eps, int silu, void* y, long y_bs, int ldy, void* workspace,
+                        hipStream_t stream) {
+  constexpr int EPC = 16 / sizeof(T);
+  if (Cn % GN_GROUPS != 0 || Cn % EPC != 0 || Cn > GN_MAX_C || ldx % EPC != 0 || ldy % EPC != 0) {
+    af_set_error_msg("groupnorm: unsupported C=%d (need C%%32==0, C%%%d==0, C<=%d)", Cn, EPC, GN_MAX_C);
+    return -1;
+  }
+  int P;
+  const int nchunk = af_gn_chunking(HW, &P);
+  float* partial = reinterpret_cast<float*>(workspace);
+  float* stats = partial + (size_t)B * nchunk * GN_GROUPS * 2;
+  hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nchunk, B), dim3(256), 0, stream,
+                     reinterpret_cast<const T*>(x), x_bs, ldx, HW, Cn, P, partial, nchunk);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, partial, nchunk,
+                     (double)HW * (double)(Cn / GN_GROUPS), eps, stats);
+  hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nchunk, B), dim3(256), 0, stream,
+                     reinterpret_cast<const T*>(x), x_bs, ldx, HW, Cn, P, stats, gamma, beta, silu,
+                     reinterpret_cast<T*>(y), y_bs, ldy);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int af_launch_layernorm(const void* x, int ldx, long rows, int Cn, const float* gamma, const float* beta,
+                        float eps, void* y, int ldy, hipStream_t stream) {
+  constexpr int EPC = 16 / sizeof(T);
+  if (Cn % EPC != 0 || Cn / EPC > 64 * LN_MAXV || ldx % EPC != 0 || ldy % EPC != 0) {
+    af_set_error_msg("layernorm: unsupported C=%d", Cn);
+    return -1;
+  }
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL((layernorm_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream,
+                     reinterpret_cast<const T*>(x), ldx, rows, Cn, gamma, beta, eps,
+                     reinterpret_cast<T*>(y), ldy);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+template int af_launch_groupnorm<bf16>(const void*, long, int, int, int, int, const float*, const float*, float,
+                                       int, void*, long, int, void*, hipStream_t);
+template int af_launch_groupnorm<float>(const void*, long, int, int, int, int, const float*, const float*, float,
+                                        int, void*, long, int, void*, hipStream_t);
+template int af_launch_layernorm<bf16>(const void*, int, long, int, const float*, const float*, float, void*, int,
+                                       hipStream_t);
+template int af_launch_layernorm<float>(const void*, int, long, int, const float*, const float*, float, void*,
+                                        int, hipStream_t);

@@ -1,0 +1,198 @@
+// Operator-level C-ABI entry points used by the parity tests (tests/test_ops_gpu.py).
+// They take fp32 device tensors in the REFERENCE's layouts (NCHW, [rows, C],
+// [B, N, heads*dh]), convert to the internal NHWC storage dtype, run exactly the
+// kernels the UNet / VAE executors use, and convert back.  Temporary buffers are
+// hipMalloc'd per call (test path only, never on the hot path).
+#include "../../include/adaface_hip.h"
+#include "af_kernels.h"
+
+#include <cstring>
+#include <vector>
+
+namespace {
+struct Tmp {
+  std::vector<void*> bufs;
+  void* get(size_t bytes, bool zero = false) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    if (zero) hipMemset(p, 0, bytes);
+    bufs.push_back(p);
+    return p;
+  }
+  ~Tmp() {
+    hipDeviceSynchronize();
+    for (void* p : bufs) hipFree(p);
+  }
+};
+inline size_t esz(int dtype) { return dtype == AF_DTYPE_BF16 ? 2 : 4; }
+inline int bk(int dtype) { return dtype == AF_DTYPE_BF16 ? 64 : 32; }
+inline int rup(int a, int b) { return (a + b - 1) / b * b; }
+}  // namespace
+
+#define OP_TRY(expr)          \
+  do {                        \
+    int _rc = (expr);         \
+    if (_rc != 0) return _rc; \
+  } while (0)
+#define DISP(dtype, A, B) ((dtype) == AF_DTYPE_BF16 ? (A) : (B))
+#define OP_ALLOC(var, bytes, zero)                               \
+  void* var = tmp.get((bytes), (zero));                          \
+  if (!var) { af_set_error_msg("hipMalloc failed in op"); return AF_ERR_HIP; }
+
+extern "C" {
+
+int af_op_conv2d(int dtype, const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev,
+                 float* y_dev, int B, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int upsample,
+                 void* stream) {
+  if ((ks != 1 && ks != 3) || pad != ks / 2) { af_set_error_msg("af_op_conv2d: ks must be 1 or 3 with pad ks/2"); return AF_ERR_INVALID; }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Tmp tmp;
+  const int cin_pad = rup(Cin, bk(dtype));
+  const int Hi = H << upsample, Wi = W << upsample;
+  const int Ho = (Hi + 2 * pad - ks) / stride + 1, Wo = (Wi + 2 * pad - ks) / stride + 1;
+  const int co4 = rup(Cout, 4), rows_pad = rup(Cout, 128), ldw = ks * ks * cin_pad;
+  OP_ALLOC(xn, (size_t)B * H * W * cin_pad * esz(dtype), false);
+  OP_ALLOC(wn, (size_t)rows_pad * ldw * esz(dtype), true);
+  OP_ALLOC(yn, (size_t)B * Ho * Wo * co4 * esz(dtype), true);
+  void* rn = nullptr;
+  float* bn = nullptr;
+  OP_TRY(DISP(dtype, af_launch_nchw_to_nhwc<bf16>(x_dev, xn, B, Cin, H * W, cin_pad, 1.f, s),
+              af_launch_nchw_to_nhwc<float>(x_dev, xn, B, Cin, H * W, cin_pad, 1.f, s)));
+  OP_TRY(DISP(dtype, af_launch_repack_weight<bf16>(w_dev, wn, Cout, Cin, cin_pad, ks, ldw, 0, 0, s),
+              af_launch_repack_weight<float>(w_dev, wn, Cout, Cin, cin_pad, ks, ldw, 0, 0, s)));
+  if (bias_dev) {
+    bn = reinterpret_cast<float*>(tmp.get((size_t)rup(Cout, 128) * 4, true));
+    if (!bn) return AF_ERR_HIP;
+    if (hipMemcpyAsync(bn, bias_dev, (size_t)Cout * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return AF_ERR_HIP;
+  }
+  if (residual_dev) {
+    rn = tmp.get((size_t)B * Ho * Wo * co4 * esz(dtype), false);
+    if (!rn) return AF_ERR_HIP;
+    OP_TRY(DISP(dtype, af_launch_nchw_to_nhwc<bf16>(residual_dev, rn, B, Cout, Ho * Wo, co4, 1.f, s),
+                af_launch_nchw_to_nhwc<float>(residual_dev, rn, B, Cout, Ho * Wo, co4, 1.f, s)));
+  }
+  ConvGemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.src = xn; p.src_batch_stride = (long)H * W * cin_pad; p.ldc = cin_pad; p.Cin = cin_pad;
+  p.Hs = H; p.Ws = W; p.up = upsample; p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo;
+  p.ks = ks; p.stride = stride; p.pad = pad;
+  p.W = wn; p.ldw = ldw; p.Wrows = rows_pad;
+  p.M = B * Ho * Wo; p.N = co4; p.K = ldw;
+  p.bias = bn; p.residual = rn; p.ldr = co4; p.out = yn; p.ldo = co4; p.alpha = 1.f;
+  OP_TRY(DISP(dtype, af_launch_conv_gemm<bf16>(p, 1, s), af_launch_conv_gemm<float>(p, 1, s)));
+  OP_TRY(DISP(dtype, af_launch_nhwc_to_nchw<bf16>(yn, y_dev, B, Cout, Ho * Wo, co4, s),
+              af_launch_nhwc_to_nchw<float>(yn, y_dev, B, Cout, Ho * Wo, co4, s)));
+  return 0;
+}
+
+int af_op_linear(int dtype, const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev,
+                 float* y_dev, int64_t M, int K, int N, int geglu, void* stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Tmp tmp;
+  const int kp = rup(K, bk(dtype));
+  const int rows = geglu ? 2 * N : N;  // weight rows
+  const int rows_pad = rup(rows, 128);
+  const int no4 = rup(N, 4);
+  OP_ALLOC(xn, (size_t)M * kp * esz(dtype), false);
+  OP_ALLOC(wn, (size_t)rows_pad * kp * esz(dtype), true);
+  OP_ALLOC(yn, (size_t)M * no4 * esz(dtype), true);
+  float* bn = nullptr;
+  void* rn = nullptr;
+  // [M,K] rows == NCHW with C=K, HW=1 per "sample": reuse the NCHW converter with B=M, HW=1
+  OP_TRY(DISP(dtype, af_launch_nchw_to_nhwc<bf16>(x_dev, xn, (int)M, K, 1, kp, 1.f, s),
+              af_launch_nchw_to_nhwc<float>(x_dev, xn, (int)M, K, 1, kp, 1.f, s)));
+  OP_TRY(DISP(dtype, af_launch_repack_weight<bf16>(w_dev, wn, rows, K, kp, 1, kp, 0, geglu ? 1 : 0, s),
+              af_launch_repack_weight<float>(w_dev, wn, rows, K, kp, 1, kp, 0, geglu ? 1 : 0, s)));
+  if (bias_dev) {
+    bn = reinterpret_cast<float*>(tmp.get((size_t)rows_pad * 4, true));
+    if (!bn) return AF_ERR_HIP;
+    OP_TRY(af_launch_permute_bias(bias_dev, bn, rows, geglu ? 1 : 0, s));
+  }
+  if (residual_dev) {
+    rn = tmp.get((size_t)M * no4 * esz(dtype), false);
+    if (!rn) return AF_ERR_HIP;
+    OP_TRY(DISP(dtype, af_launch_nchw_to_nhwc<bf16>(residual_dev, rn, (int)M, N, 1, no4, 1.f, s),
+                af_launch_nchw_to_nhwc<float>(residual_dev, rn, (int)M, N, 1, no4, 1.f, s)));
+  }
+  ConvGemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.src = xn; p.src_batch_stride = (long)M * kp; p.ldc = kp; p.Cin = kp;
+  p.Hs = 1; p.Ws = (int)M; p.Hi = 1; p.Wi = (int)M; p.Ho = 1; p.Wo = (int)M;
+  p.ks = 1; p.stride = 1; p.pad = 0;
+  p.W = wn; p.ldw = kp; p.Wrows = rows_pad;
+  p.M = (int)M; p.N = geglu ? 2 * N : no4; p.K = kp;
+  p.bias = bn; p.residual = rn; p.ldr = no4; p.out = yn; p.ldo = no4;
+  p.epilogue = geglu ? AF_EPI_GEGLU : AF_EPI_NONE;
+  p.alpha = 1.f;
+  OP_TRY(DISP(dtype, af_launch_conv_gemm<bf16>(p, 1, s), af_launch_conv_gemm<float>(p, 1, s)));
+  OP_TRY(DISP(dtype, af_launch_nhwc_to_nchw<bf16>(yn, y_dev, (int)M, N, 1, no4, s),
+              af_launch_nhwc_to_nchw<float>(yn, y_dev, (int)M, N, 1, no4, s)));
+  return 0;
+}
+
+int af_op_groupnorm(int dtype, const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, int silu,
+                    float* y_dev, int B, int C, int H, int W, void* stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Tmp tmp;
+  const int HW = H * W;
+  OP_ALLOC(xn, (size_t)B * HW * C * esz(dtype), false);
+  OP_ALLOC(yn, (size_t)B * HW * C * esz(dtype), false);
+  OP_ALLOC(ws, af_gn_workspace_bytes(B, HW), false);
+  OP_TRY(DISP(dtype, af_launch_nchw_to_nhwc<bf16>(x_dev, xn, B, C, HW, C, 1.f, s),
+              af_launch_nchw_to_nhwc<float>(x_dev, xn, B, C, HW, C, 1.f, s)));
+  OP_TRY(DISP(dtype,
+              af_launch_groupnorm<bf16>(xn, (long)HW * C, C, B, HW, C, gamma_dev, beta_dev, eps, silu, yn, (long)HW * C, C, ws, s),
+              af_launch_groupnorm<float>(xn, (long)HW * C, C, B, HW, C, gamma_dev, beta_dev, eps, silu, yn, (long)HW * C, C, ws, s)));
+  OP_TRY(DISP(dtype, af_launch_nhwc_to_nchw<bf16>(yn, y_dev, B, C, HW, C, s),
+              af_launch_nhwc_to_nchw<float>(yn, y_dev, B, C, HW, C, s)));
+  return 0;
+}
+
+int af_op_layernorm(int dtype, const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps,
+                    float* y_dev, int64_t rows, int C, void* stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Tmp tmp;
+  OP_ALLOC(xn, (size_t)rows * C * esz(dtype), false);
+  OP_ALLOC(yn, (size_t)rows * C * esz(dtype), false);
+  OP_TRY(DISP(dtype, af_launch_cast_f32<bf16>(x_dev, xn, rows * C, s), af_launch_cast_f32<float>(x_dev, xn, rows * C, s)));
+  OP_TRY(DISP(dtype, af_launch_layernorm<bf16>(xn, C, rows, C, gamma_dev, beta_dev, eps, yn, C, s),
+              af_launch_layernorm<float>(xn, C, rows, C, gamma_dev, beta_dev, eps, yn, C, s)));
+  OP_TRY(DISP(dtype, af_launch_cast_to_f32<bf16>(yn, y_dev, rows * C, s), af_launch_cast_to_f32<float>(yn, y_dev, rows * C, s)));
+  return 0;
+}
+
+int af_op_attention(int dtype, const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int B, int Nq,
+                    int Nk, int heads, int dh, float scale, void* stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Tmp tmp;
+  const int C = heads * dh;
+  const long nq = (long)B * Nq * C, nk = (long)B * Nk * C;
+  OP_ALLOC(qn, (size_t)nq * esz(dtype), false);
+  OP_ALLOC(kn, (size_t)nk * esz(dtype), false);
+  OP_ALLOC(vn, (size_t)nk * esz(dtype), false);
+  OP_ALLOC(on, (size_t)nq * esz(dtype), true);
+  OP_TRY(DISP(dtype, af_launch_cast_f32<bf16>(q_dev, qn, nq, s), af_launch_cast_f32<float>(q_dev, qn, nq, s)));
+  OP_TRY(DISP(dtype, af_launch_cast_f32<bf16>(k_dev, kn, nk, s), af_launch_cast_f32<float>(k_dev, kn, nk, s)));
+  OP_TRY(DISP(dtype, af_launch_cast_f32<bf16>(v_dev, vn, nk, s), af_launch_cast_f32<float>(v_dev, vn, nk, s)));
+  AttnParams p;
+  p.q = qn; p.k = kn; p.v = vn; p.o = on;
+  p.ldq = p.ldk = p.ldv = p.ldo = C;
+  p.bsq = (long)Nq * C; p.bso = (long)Nq * C; p.bsk = (long)Nk * C; p.bsv = (long)Nk * C;
+  p.Nq = Nq; p.Nk = Nk; p.H = heads; p.scale = scale;
+  OP_TRY(DISP(dtype, af_launch_attention<bf16>(p, B, dh, s), af_launch_attention<float>(p, B, dh, s)));
+  OP_TRY(DISP(dtype, af_launch_cast_to_f32<bf16>(on, o_dev, nq, s), af_launch_cast_to_f32<float>(on, o_dev, nq, s)));
+  return 0;
+}
+
+int af_op_timestep_embedding(int dtype, const int64_t* t_dev, float* y_dev, int B, int dim, void* stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Tmp tmp;
+  OP_ALLOC(yn, (size_t)B * dim * esz(dtype), false);
+  OP_TRY(DISP(dtype, af_launch_timestep_embedding<bf16>((const long long*)t_dev, yn, B, dim, s),
+              af_launch_timestep_embedding<float>((const long long*)t_dev, yn, B, dim, s)));
+  OP_TRY(DISP(dtype, af_launch_cast_to_f32<bf16>(yn, y_dev, (long)B * dim, s),
+              af_launch_cast_to_f32<float>(yn, y_dev, (long)B * dim, s)));
+  return 0;
+}
+
+}  // extern "C"

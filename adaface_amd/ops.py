@@ -1,0 +1,127 @@
+"""Operator-level wrappers over the C ABI (af_op_* in include/adaface_hip.h).
+
+Same names / argument meaning as the torch.nn.functional calls the reference makes on
+the hot path, operating on fp32 CUDA(HIP) tensors in the reference's
+layouts.  `dtype` selects the kernels' storage/MFMA type: "bf16" or "f32".
+Used by the parity tests and by nobody on the hot path (the model executors call the
+same kernels internally with no conversions).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+from ._lib import DTYPES, check, ptr, stream_ptr
+
+
+def _dev_f32(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError("adaface_amd.ops: tensors must live on the GPU (no CPU path)")
+    return t.contiguous().float()
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=None, upsample=False, residual=None, dtype="bf16"):
+    """F.conv2d(F.interpolate(x, 2, 'nearest') if upsample else x, weight, bias, stride, padding) [+ residual]."""
+    lib = _lib.load()
+    x, weight = _dev_f32(x), _dev_f32(weight)
+    B, Cin, H, W = x.shape
+    Cout, Cin2, ks, ks2 = weight.shape
+    if Cin2 != Cin or ks != ks2:
+        raise ValueError(f"conv2d: weight {tuple(weight.shape)} does not match input {tuple(x.shape)}")
+    pad = ks // 2 if padding is None else padding
+    up = 1 if upsample else 0
+    Hi, Wi = H << up, W << up
+    Ho, Wo = (Hi + 2 * pad - ks) // stride + 1, (Wi + 2 * pad - ks) // stride + 1
+    y = torch.empty(B, Cout, Ho, Wo, device=x.device, dtype=torch.float32)
+    b = None if bias is None else _dev_f32(bias)
+    r = None if residual is None else _dev_f32(residual)
+    check(lib.af_op_conv2d(DTYPES[dtype], ptr(x), ptr(weight), ptr(b), ptr(r), ptr(y), B, Cin, H, W, Cout, ks, stride,
+                           pad, up, stream_ptr()), "af_op_conv2d")
+    return y
+
+
+def linear(x, weight, bias=None, residual=None, geglu=False, dtype="bf16"):
+    """F.linear over the last dim; geglu=True applies GEGLU (attention.py:32-45) to the projection."""
+    lib = _lib.load()
+    x, weight = _dev_f32(x), _dev_f32(weight)
+    K = x.shape[-1]
+    M = x.numel() // K
+    rows = weight.shape[0]
+    N = rows // 2 if geglu else rows
+    y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+    b = None if bias is None else _dev_f32(bias)
+    r = None if residual is None else _dev_f32(residual)
+    check(lib.af_op_linear(DTYPES[dtype], ptr(x), ptr(weight), ptr(b), ptr(r), ptr(y), M, K, N, 1 if geglu else 0,
+                           stream_ptr()), "af_op_linear")
+    return y
+
+
+def group_norm(x, weight, bias, eps=1e-5, silu=False, dtype="bf16"):
+    """F.group_norm(x, 32, weight, bias, eps) (+ SiLU)."""
+    lib = _lib.load()
+    x = _dev_f32(x)
+    B, Cn, H, W = x.shape
+    y = torch.empty_like(x)
+    check(lib.af_op_groupnorm(DTYPES[dtype], ptr(x), ptr(_dev_f32(weight)), ptr(_dev_f32(bias)), eps, 1 if silu else 0,
+                              ptr(y), B, Cn, H, W, stream_ptr()), "af_op_groupnorm")
+    return y
+
+
+def layer_norm(x, weight, bias, eps=1e-5, dtype="bf16"):
+    lib = _lib.load()
+    x = _dev_f32(x)
+    Cn = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib.af_op_layernorm(DTYPES[dtype], ptr(x), ptr(_dev_f32(weight)), ptr(_dev_f32(bias)), eps, ptr(y),
+                              x.numel() // Cn, Cn, stream_ptr()), "af_op_layernorm")
+    return y
+
+
+def attention(q, k, v, heads, scale=None, dtype="bf16"):
+    """softmax(q k^T * scale) v per head; q [B,N,heads*dh], k/v [B,S,heads*dh] (attention.py:197-243)."""
+    lib = _lib.load()
+    q, k, v = _dev_f32(q), _dev_f32(k), _dev_f32(v)
+    B, Nq, Cn = q.shape
+    Nk = k.shape[1]
+    dh = Cn // heads
+    scale = dh ** -0.5 if scale is None else scale
+    o = torch.empty_like(q)
+    check(lib.af_op_attention(DTYPES[dtype], ptr(q), ptr(k), ptr(v), ptr(o), B, Nq, Nk, heads, dh, scale, stream_ptr()),
+          "af_op_attention")
+    return o
+
+
+def timestep_embedding(t, dim, dtype="f32"):
+    lib = _lib.load()
+    t = t.contiguous().long()
+    y = torch.empty(t.shape[0], dim, device=t.device, dtype=torch.float32)
+    check(lib.af_op_timestep_embedding(DTYPES[dtype], ptr(t), ptr(y), t.shape[0], dim, stream_ptr()),
+          "af_op_timestep_embedding")
+    return y
+
+
+def ddim_step(x, e_cond, e_uncond, guidance, a_t, a_prev, sqrt_one_minus_at, sigma_t=0.0, noise=None, temperature=1.0):
+    """CFG combine + DDIM update (ddim.py:260,279-295); returns (x_prev, pred_x0)."""
+    lib = _lib.load()
+    x, e_cond = _dev_f32(x), _dev_f32(e_cond)
+    eu = None if e_uncond is None else _dev_f32(e_uncond)
+    nz = None if noise is None else _dev_f32(noise)
+    x_prev, pred_x0 = torch.empty_like(x), torch.empty_like(x)
+    check(lib.af_ddim_step(ptr(x), ptr(e_cond), ptr(eu), ptr(nz), x.numel(), float(guidance), float(a_t), float(a_prev),
+                           float(sqrt_one_minus_at), float(sigma_t), float(temperature), ptr(x_prev), ptr(pred_x0),
+                           stream_ptr()), "af_ddim_step")
+    return x_prev, pred_x0
+
+
+def to_uint8(img):
+    """clamp((img+1)/2,0,1)*255 -> uint8 HWC (stable_txt2img.py:715,764-765)."""
+    lib = _lib.load()
+    img = _dev_f32(img)
+    B, Cn, H, W = img.shape
+    if Cn != 3:
+        raise ValueError("to_uint8 expects [B,3,H,W]")
+    y = torch.empty(B, H, W, 3, device=img.device, dtype=torch.uint8)
+    check(lib.af_to_uint8(ptr(img), ptr(y), B, H, W, stream_ptr()), "af_to_uint8")
+    return y

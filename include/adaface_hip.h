@@ -1,0 +1,126 @@
+/* adaface_hip.h — C ABI of libadaface_hip.so, the MI355X (gfx950) denoising path.
+ *
+ * The reference (zyt334/AdaFace) has NO FFI / plugin ABI: its seam is Python — yaml
+ * `target:` strings resolved by ldm/util.py:105-112 (instantiate_from_config) and
+ * duck-typed calls from scripts/stable_txt2img.py:701-715.  This header is therefore
+ * the contract the Python classes in adaface_amd/ldm/ bind with ctypes; each entry
+ * point cites the reference function it replaces.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; af_last_error() has the text
+ *   - `*_dev` pointers are device (HBM) pointers owned by the caller (PyTorch);
+ *     the library never frees or retains them past the call (stream-ordered)
+ *   - tensors crossing the boundary use the REFERENCE's layout and dtype
+ *     (NCHW float32, int64 timesteps); NHWC bf16/f32 is internal
+ *   - `stream` is a hipStream_t (0 = default stream); a handle is not thread-safe
+ */
+#ifndef ADAFACE_HIP_H
+#define ADAFACE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct af_handle af_handle;
+
+enum { AF_DTYPE_BF16 = 0, AF_DTYPE_F32 = 1 };
+enum {
+  AF_OK = 0,
+  AF_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+  AF_ERR_HIP = -2,       /* HIP runtime error */
+  AF_ERR_NAME = -3,      /* unknown tensor name */
+  AF_ERR_STATE = -4      /* call sequence error (weights/context missing) */
+};
+
+/* Mirrors the constructor kwargs of UNetModel (ldm/modules/diffusionmodules/openaimodel.py:447-473)
+ * and Decoder / AutoencoderKL (ldm/modules/diffusionmodules/model.py:502-507,
+ * ldm/models/autoencoder.py:286-300) as used by configs/stable-diffusion/v1-inference-ada.yaml:35-76. */
+typedef struct af_config {
+  int dtype;                      /* AF_DTYPE_BF16 (throughput) or AF_DTYPE_F32 (parity) */
+  /* UNet */
+  int build_unet;
+  int in_channels, model_channels, out_channels, num_res_blocks;
+  int n_attention_resolutions, attention_resolutions[8];
+  int n_channel_mult, channel_mult[8];
+  int num_heads, context_dim, transformer_depth;
+  int n_context_layers;           /* 16 = AdaFace layerwise context, openaimodel.py:863-883 */
+  /* VAE decoder */
+  int build_vae;
+  int vae_ch, vae_out_ch, vae_num_res_blocks, vae_z_channels, vae_embed_dim;
+  int n_vae_ch_mult, vae_ch_mult[8];
+} af_config;
+
+const char* af_last_error(void);
+int af_version(void);
+
+/* LatentDiffusion.__init__ model assembly + model.to(device)
+ * (ldm/models/diffusion/ddpm.py:714-813, scripts/stable_txt2img.py:428). */
+int af_create(int device_id, const af_config* cfg, af_handle** out);
+void af_destroy(af_handle* h);
+
+/* model.load_state_dict (ldm/util.py:129): one call per state_dict entry, fp32 HOST data.
+ * `name` is the checkpoint key: "model.diffusion_model.<k>" or "first_stage_model.<k>". */
+int af_load_tensor(af_handle* h, const char* name, const float* host_data, int ndim, const int64_t* shape);
+int af_num_tensors(af_handle* h);
+const char* af_tensor_name(af_handle* h, int i);
+int af_tensor_loaded(af_handle* h, int i);
+int af_tensor_shape(af_handle* h, int i, int64_t* shape4 /* up to 4 dims, 0-terminated */);
+
+/* get_layer_context + to_k/to_v of all cross-attention layers, hoisted out of the
+ * step loop (openaimodel.py:863-920, attention.py:195-196).  ctx_dev: fp32
+ * [Bf*n_layers, n_tokens, context_dim] laid out as the reference does
+ * (layer index inside the batch axis, embedding_manager.py:1342-1353), or
+ * [Bf, n_tokens, context_dim] when layerwise == 0. */
+int af_set_context(af_handle* h, const float* ctx_dev, int Bf, int n_tokens, int layerwise, void* stream);
+
+/* UNetModel.forward (openaimodel.py:827-1052): x_dev [Bf,Cin,H,W] fp32 NCHW,
+ * t_dev [Bf] int64, eps_dev [Bf,Cout,H,W] fp32 NCHW.  Uses the context set above. */
+int af_unet_forward(af_handle* h, const float* x_dev, const int64_t* t_dev, float* eps_dev, int Bf, int H, int W,
+                    void* stream);
+
+/* p_sample_ddim's CFG combine + x_{t-1} update (ddim.py:260,273-295), fp32, n elements.
+ * eps_uncond_dev / noise_dev / pred_x0_dev may be NULL. */
+int af_ddim_step(const float* x_dev, const float* eps_cond_dev, const float* eps_uncond_dev, const float* noise_dev,
+                 int64_t n, float guidance, float a_t, float a_prev, float sqrt_one_minus_at, float sigma_t,
+                 float temperature, float* x_prev_dev, float* pred_x0_dev, void* stream);
+
+/* decode_first_stage + AutoencoderKL.decode (ddpm.py:1251-1308, autoencoder.py:330-333):
+ * z_dev [B,zc,H,W] fp32 -> img_dev [B,out_ch,8H,8W] fp32 NCHW (may be NULL) and/or
+ * u8_dev [B,8H,8W,3] uint8 HWC = clamp((x+1)/2,0,1)*255 truncated (stable_txt2img.py:715,764-765). */
+int af_vae_decode(af_handle* h, const float* z_dev, float scale_factor, float* img_dev, uint8_t* u8_dev, int B, int H,
+                  int W, void* stream);
+
+/* clamp((x+1)/2,0,1)*255 -> uint8 HWC from an fp32 NCHW image [B,3,H,W]. */
+int af_to_uint8(const float* img_dev, uint8_t* u8_dev, int B, int H, int W, void* stream);
+
+/* bytes of the activation arena currently reserved by the handle (diagnostics) */
+int64_t af_arena_bytes(af_handle* h);
+
+/* ---- operator-level entry points (parity tests; reference layouts, fp32 device tensors) ----
+ * Each converts to the internal NHWC `dtype` layout, runs the same kernel the model
+ * uses, and converts back. */
+/* F.conv2d(x, w, b, stride, padding) with optional nearest-2x upsample of x first;
+ * w [Cout,Cin,k,k] (k = 1 or 3), residual / out NCHW [B,Cout,Ho,Wo]. */
+int af_op_conv2d(int dtype, const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev,
+                 float* y_dev, int B, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int upsample,
+                 void* stream);
+/* F.linear on [M,K] rows: y = x w^T + b (+ residual); geglu != 0: w is [2*Nout,K] and
+ * y [M,Nout] = value * gelu(gate)  (attention.py:32-45). */
+int af_op_linear(int dtype, const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev,
+                 float* y_dev, int64_t M, int K, int N, int geglu, void* stream);
+/* F.group_norm(x, 32, gamma, beta, eps) on NCHW, optional SiLU. */
+int af_op_groupnorm(int dtype, const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, int silu,
+                    float* y_dev, int B, int C, int H, int W, void* stream);
+/* F.layer_norm over the last dim of [rows, C]. */
+int af_op_layernorm(int dtype, const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps,
+                    float* y_dev, int64_t rows, int C, void* stream);
+/* multi-head attention on [B,N,heads*dh] / [B,S,heads*dh] tensors (attention.py:197-243). */
+int af_op_attention(int dtype, const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int B, int Nq,
+                    int Nk, int heads, int dh, float scale, void* stream);
+/* timestep_embedding (util.py:154-174): t [B] int64 -> y [B,dim] fp32. */
+int af_op_timestep_embedding(int dtype, const int64_t* t_dev, float* y_dev, int B, int dim, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,208 @@
+"""GPU parity of every hot-path operator against the torch fp32 CPU op the reference calls.
+
+Each HIP kernel is reached through the C ABI (af_op_*).  Two storage/MFMA modes:
+  f32  : parity mode (f32 MFMA, exact fp32 products) — tolerance 2e-4 of the output scale
+  bf16 : throughput mode (bf16 MFMA, fp32 accumulate)  — tolerance 3e-2 of the output scale
+Tolerances are relative to max|reference| and are stated here, not tuned per case.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": 2e-4, "bf16": 3e-2}
+
+
+def _cmp(report, name, got, ref, dtype, tol_scale=1.0):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = ref.abs().max().item() + 1e-12
+    finite = bool(torch.isfinite(got).all())
+    err = (got - ref).abs().max().item() if finite else float("inf")
+    tol = TOL[dtype] * tol_scale
+    report(f"{name}[{dtype}]", err, scale, tol * scale)
+    assert finite, f"{name}[{dtype}]: non-finite output"
+    assert err <= tol * scale, f"{name}[{dtype}]: max abs err {err:.3e} > {tol:.1e} * {scale:.3e}"
+
+
+def _q(t, dtype):
+    """Round inputs to the kernel's storage type so the comparison isolates kernel arithmetic."""
+    return t.to(torch.bfloat16).float() if dtype == "bf16" else t
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("B,C,H,W,eps,silu", [
+    (2, 320, 64, 64, 1e-5, True), (2, 640, 32, 32, 1e-5, True), (1, 960, 64, 64, 1e-5, True),
+    (2, 1280, 8, 8, 1e-6, False), (1, 2560, 16, 16, 1e-5, True), (1, 1920, 32, 32, 1e-5, True),
+    (1, 128, 96, 80, 1e-6, True), (3, 64, 4, 4, 1e-6, False), (1, 512, 128, 128, 1e-6, True),
+])
+def test_groupnorm(gpu, report, dtype, B, C, H, W, eps, silu):
+    from adaface_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    x = _q(torch.randn(B, C, H, W, generator=g) * 1.7 + 0.4, dtype)
+    w = torch.randn(C, generator=g) * 0.3 + 1.0
+    b = torch.randn(C, generator=g) * 0.2
+    ref = F.group_norm(x, 32, w, b, eps)
+    if silu:
+        ref = F.silu(ref)
+    got = ops.group_norm(x.to(gpu), w.to(gpu), b.to(gpu), eps=eps, silu=silu, dtype=dtype)
+    _cmp(report, f"groupnorm C{C} {H}x{W}", got, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("rows,C", [(4096, 320), (1024, 640), (256, 1280), (7, 64), (130, 1280)])
+def test_layernorm(gpu, report, dtype, rows, C):
+    from adaface_amd import ops
+    g = torch.Generator().manual_seed(rows + C)
+    x = _q(torch.randn(rows, C, generator=g) * 2.0 + 0.5, dtype)
+    w = torch.randn(C, generator=g) * 0.3 + 1.0
+    b = torch.randn(C, generator=g) * 0.2
+    ref = F.layer_norm(x, (C,), w, b, 1e-5)
+    got = ops.layer_norm(x.to(gpu), w.to(gpu), b.to(gpu), dtype=dtype)
+    _cmp(report, f"layernorm {rows}x{C}", got, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("M,K,N,bias,res", [
+    (4096, 320, 320, True, True), (1024, 640, 640, False, False), (77 * 2, 768, 1280, False, False),
+    (2, 320, 1280, True, False), (256, 1280, 1280, True, True), (200, 64, 192, True, False),
+    (4096, 1280, 320, True, True), (333, 128, 4, True, False),
+])
+def test_linear(gpu, report, dtype, M, K, N, bias, res):
+    from adaface_amd import ops
+    g = torch.Generator().manual_seed(M + K + N)
+    x = _q(torch.randn(M, K, generator=g), dtype)
+    w = _q(torch.randn(N, K, generator=g) / math.sqrt(K), dtype)
+    b = torch.randn(N, generator=g) * 0.1 if bias else None
+    r = _q(torch.randn(M, N, generator=g), dtype) if res else None
+    ref = F.linear(x, w, b)
+    if res:
+        ref = ref + r
+    got = ops.linear(x.to(gpu), w.to(gpu), None if b is None else b.to(gpu), None if r is None else r.to(gpu),
+                     dtype=dtype)
+    _cmp(report, f"linear {M}x{K}->{N}", got, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("M,d", [(4096, 320), (1024, 640), (256, 1280), (70, 64)])
+def test_geglu(gpu, report, dtype, M, d):
+    """FeedForward's GEGLU projection (attention.py:32-45): Linear(d, 8d) -> value * gelu(gate)."""
+    from adaface_amd import ops
+    g = torch.Generator().manual_seed(M + d)
+    x = _q(torch.randn(M, d, generator=g), dtype)
+    w = _q(torch.randn(8 * d, d, generator=g) / math.sqrt(d), dtype)
+    b = torch.randn(8 * d, generator=g) * 0.1
+    val, gate = F.linear(x, w, b).chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    got = ops.linear(x.to(gpu), w.to(gpu), b.to(gpu), geglu=True, dtype=dtype)
+    _cmp(report, f"geglu {M}x{d}", got, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("B,Cin,H,W,Cout,ks,stride,up,bias,res", [
+    (2, 320, 32, 32, 320, 3, 1, False, True, True),     # ResBlock conv
+    (1, 4, 64, 64, 320, 3, 1, False, True, False),      # input_blocks.0
+    (1, 320, 64, 64, 4, 3, 1, False, True, False),      # out conv
+    (2, 320, 32, 32, 320, 3, 2, False, True, False),    # Downsample
+    (1, 640, 16, 16, 640, 3, 1, True, True, False),     # Upsample (nearest 2x folded in)
+    (2, 960, 16, 16, 640, 1, 1, False, True, False),    # skip_connection 1x1
+    (1, 128, 40, 24, 3, 3, 1, False, True, False),      # VAE conv_out, ragged M
+    (1, 64, 8, 8, 128, 3, 1, False, False, False),      # tiny-config conv
+    (2, 1280, 8, 8, 1280, 3, 1, False, True, True),     # deep-K small-M
+])
+def test_conv2d(gpu, report, dtype, B, Cin, H, W, Cout, ks, stride, up, bias, res):
+    from adaface_amd import ops
+    g = torch.Generator().manual_seed(Cin + Cout + H + ks)
+    x = _q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = _q(torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks), dtype)
+    b = torch.randn(Cout, generator=g) * 0.1 if bias else None
+    xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    ref = F.conv2d(xi, w, b, stride=stride, padding=ks // 2)
+    r = _q(torch.randn(ref.shape, generator=g), dtype) if res else None
+    if res:
+        ref = ref + r
+    got = ops.conv2d(x.to(gpu), w.to(gpu), None if b is None else b.to(gpu), stride=stride, upsample=up,
+                     residual=None if r is None else r.to(gpu), dtype=dtype)
+    _cmp(report, f"conv{ks}x{ks} {Cin}->{Cout}@{H}x{W} s{stride} up{int(up)}", got, ref, dtype)
+
+
+def _ref_attention(q, k, v, heads):
+    B, N, C = q.shape
+    dh = C // heads
+    qh = q.view(B, N, heads, dh).transpose(1, 2)
+    kh = k.view(B, -1, heads, dh).transpose(1, 2)
+    vh = v.view(B, -1, heads, dh).transpose(1, 2)
+    sim = torch.einsum("bhid,bhjd->bhij", qh, kh) * dh ** -0.5
+    out = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), vh)
+    return out.transpose(1, 2).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("B,Nq,Nk,heads,dh", [
+    (1, 1024, 1024, 8, 40), (1, 256, 256, 8, 80), (2, 64, 64, 8, 160), (2, 1024, 77, 8, 40),
+    (1, 256, 77, 8, 160), (1, 64, 77, 8, 160), (1, 100, 50, 2, 32), (1, 16, 16, 8, 8), (2, 4, 77, 8, 16),
+    (1, 300, 300, 2, 64), (1, 256, 77, 2, 128),
+])
+def test_attention(gpu, report, dtype, B, Nq, Nk, heads, dh):
+    from adaface_amd import ops
+    g = torch.Generator().manual_seed(Nq + Nk + dh)
+    C = heads * dh
+    q = _q(torch.randn(B, Nq, C, generator=g), dtype)
+    k = _q(torch.randn(B, Nk, C, generator=g), dtype)
+    v = _q(torch.randn(B, Nk, C, generator=g), dtype)
+    ref = _ref_attention(q, k, v, heads)
+    got = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), heads, dtype=dtype)
+    _cmp(report, f"attention N{Nq} S{Nk} h{heads} d{dh}", got, ref, dtype)
+
+
+def test_attention_spiky_softmax(gpu, report):
+    """Online-softmax rescale path: one key dominates from a late tile (forces the running max to jump)."""
+    from adaface_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, N, heads, dh = 1, 256, 2, 64
+    q = torch.randn(B, N, heads * dh, generator=g)
+    k = torch.randn(B, N, heads * dh, generator=g)
+    v = torch.randn(B, N, heads * dh, generator=g)
+    k[:, 200] = q[:, 17] * 3.0  # key 200 (4th tile) matches query 17 strongly
+    ref = _ref_attention(q, k, v, heads)
+    got = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), heads, dtype="f32")
+    _cmp(report, "attention spiky", got, ref, "f32")
+
+
+def test_timestep_embedding(gpu, report):
+    from adaface_amd import ops
+    t = torch.tensor([981, 1, 500, 21], dtype=torch.long)
+    dim, half = 320, 160
+    freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    ref = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    got = ops.timestep_embedding(t.to(gpu), dim, dtype="f32")
+    _cmp(report, "timestep_embedding", got, ref, "f32", tol_scale=0.5)
+
+
+def test_ddim_step(gpu, report):
+    from adaface_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x, ec, eu = (torch.randn(2, 4, 64, 64, generator=g) for _ in range(3))
+    a_t, a_prev, gs = 0.3521, 0.4012, 7.5
+    e = eu + gs * (ec - eu)
+    pred = (x - math.sqrt(1 - a_t) * e) / math.sqrt(a_t)
+    ref = math.sqrt(a_prev) * pred + math.sqrt(1 - a_prev) * e
+    xp, p0 = ops.ddim_step(x.to(gpu), ec.to(gpu), eu.to(gpu), gs, a_t, a_prev, math.sqrt(1 - a_t))
+    _cmp(report, "ddim x_prev", xp, ref, "f32", tol_scale=0.05)
+    _cmp(report, "ddim pred_x0", p0, pred, "f32", tol_scale=0.05)
+
+
+def test_to_uint8(gpu):
+    from adaface_amd import ops
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(2, 3, 32, 48, generator=g)
+    ref = (torch.clamp((img + 1) / 2, 0, 1).permute(0, 2, 3, 1).numpy() * 255).astype("uint8")
+    got = ops.to_uint8(img.to(gpu)).cpu().numpy()
+    # identical arithmetic up to fp32 rounding of x*255: allow off-by-one on exact boundaries
+    assert (abs(got.astype(int) - ref.astype(int)) <= 1).all()
+    assert (got != ref).mean() < 1e-3
