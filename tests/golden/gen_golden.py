@@ -1,0 +1,232 @@
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own modules
+(/root/reference, CPU fp32) on seeded synthetic weights and inputs.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+What is imported from the reference: ldm.modules.diffusionmodules.openaimodel.UNetModel,
+ldm.modules.diffusionmodules.model.Decoder, ldm.models.diffusion.ddim.DDIMSampler and the
+schedule helpers of ldm.modules.diffusionmodules.util — after registering three inert stub
+modules for packages the reference imports at module import time but never uses on this path
+(torchvision.utils / cv2 for image grids, omegaconf.listconfig for one isinstance check),
+exactly as recorded in SURVEY.md §8c.  No reference source is copied: only inputs and
+outputs are stored.  Weights are produced by oracle.ldm_oracle.synth_state_dict (seeded), so
+the fixtures hold only small input/output tensors.
+"""
+from __future__ import annotations
+
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+REF = "/root/reference"
+OUT = Path(__file__).resolve().parent
+
+
+def _stub_modules():
+    tv = types.ModuleType("torchvision")
+    tvu = types.ModuleType("torchvision.utils")
+    tvu.make_grid = lambda *a, **k: None
+    tvu.draw_bounding_boxes = lambda *a, **k: None
+    tv.utils = tvu
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.utils", tvu)
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    oc = types.ModuleType("omegaconf")
+    ocl = types.ModuleType("omegaconf.listconfig")
+
+    class ListConfig(list):
+        pass
+    ocl.ListConfig = ListConfig
+    oc.listconfig = ocl
+    sys.modules.setdefault("omegaconf", oc)
+    sys.modules.setdefault("omegaconf.listconfig", ocl)
+
+
+def main():
+    _stub_modules()
+    sys.path.insert(0, REF)
+    torch.set_grad_enabled(False)
+    torch.manual_seed(0)
+    from oracle import ldm_oracle as O
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from ldm.modules.diffusionmodules.model import Decoder
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.modules.diffusionmodules import util as rutil
+
+    def ref_unet(cfg: O.UNetConfig):
+        m = UNetModel(image_size=32, in_channels=cfg.in_channels, model_channels=cfg.model_channels,
+                      out_channels=cfg.out_channels, num_res_blocks=cfg.num_res_blocks,
+                      attention_resolutions=list(cfg.attention_resolutions), channel_mult=list(cfg.channel_mult),
+                      num_heads=cfg.num_heads, use_spatial_transformer=True, transformer_depth=cfg.transformer_depth,
+                      context_dim=cfg.context_dim, use_checkpoint=True, legacy=False)
+        return m.eval()
+
+    def load(module, sd, prefix):
+        own = module.state_dict()
+        stripped = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        assert set(own) == set(stripped), (sorted(set(own) ^ set(stripped))[:10])
+        for k in own:
+            assert tuple(own[k].shape) == tuple(stripped[k].shape), (k, own[k].shape, stripped[k].shape)
+        module.load_state_dict(stripped, strict=True)
+
+    def extra_info():
+        return {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "placeholder2indices": None,
+                "is_training": False}
+
+    g = torch.Generator().manual_seed(1234)
+    golden = {}
+
+    # ---- schedule tables (ddpm.py:244-265, util.py:21-77, ddim.py:169-218) ----
+    betas = rutil.make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.0120)
+    acp = np.cumprod(1.0 - betas, axis=0)
+    golden["sched_betas"] = np.asarray(betas, dtype=np.float64)
+    golden["sched_alphas_cumprod"] = acp.astype(np.float64)
+    for S in (10, 50):
+        ts = rutil.make_ddim_timesteps("uniform", S, 1000, verbose=False)
+        sig, a, ap = rutil.make_ddim_sampling_parameters(torch.tensor(acp, dtype=torch.float32), ts, 0.0, verbose=False)
+        golden[f"ddim_timesteps_S{S}"] = np.asarray(ts)
+        golden[f"ddim_alphas_S{S}"] = a.numpy()
+        golden[f"ddim_alphas_prev_S{S}"] = np.asarray(ap)
+        golden[f"ddim_sigmas_S{S}"] = np.asarray(sig)
+    t = torch.tensor([981, 1, 500, 21])
+    golden["temb_t"] = t.numpy()
+    golden["temb_320"] = rutil.timestep_embedding(t, 320).numpy()
+
+    # ---- tiny UNet: every block output + eps ----
+    cfg = O.TINY_UNET
+    sd = O.synth_state_dict(O.unet_param_shapes(cfg), seed=11)
+    net = ref_unet(cfg)
+    load(net, sd, O.UNET_PREFIX)
+    Bf, H = 2, 16
+    x = torch.randn(Bf, 4, H, H, generator=g)
+    tt = torch.tensor([981, 21])
+    ctx = torch.randn(Bf * 16, 77, cfg.context_dim, generator=g)
+    taps = {}
+    hooks = []
+    for i, m in enumerate(net.input_blocks):
+        hooks.append(m.register_forward_hook(lambda mod, a, o, k=f"input_blocks.{i}": taps.__setitem__(k, o)))
+    hooks.append(net.middle_block.register_forward_hook(lambda mod, a, o: taps.__setitem__("middle_block", o)))
+    for i, m in enumerate(net.output_blocks):
+        hooks.append(m.register_forward_hook(lambda mod, a, o, k=f"output_blocks.{i}": taps.__setitem__(k, o)))
+    eps = net(x, tt, context=ctx, extra_info=extra_info())
+    for hk in hooks:
+        hk.remove()
+    golden["tiny_x"], golden["tiny_t"], golden["tiny_ctx"] = x.numpy(), tt.numpy(), ctx.numpy()
+    golden["tiny_eps"] = eps.numpy()
+    for k, v in taps.items():
+        # per-block summary: mean, std, and a fixed strided sample of values
+        flat = v.reshape(-1)
+        golden[f"tiny_tap_{k}_stats"] = np.array([flat.mean().item(), flat.std().item()], dtype=np.float64)
+        golden[f"tiny_tap_{k}_sample"] = flat[:: max(1, flat.numel() // 64)][:64].numpy()
+
+    # ---- tiny UNet driven by the reference DDIMSampler (S=5, annealed guidance [10,4]) ----
+    class FakeLDM:
+        """Minimal stand-in for LatentDiffusion: the attributes DDIMSampler reads (ddim.py:19,40-46)."""
+        def __init__(self, unet):
+            self.unet = unet
+            self.num_timesteps = 1000
+            self.betas = torch.tensor(betas, dtype=torch.float32)
+            self.alphas_cumprod = torch.tensor(acp, dtype=torch.float32)
+            self.alphas_cumprod_prev = torch.tensor(np.append(1.0, acp[:-1]), dtype=torch.float32)
+            self.device = torch.device("cpu")
+            self.trace = []
+
+        def apply_model(self, x_noisy, t_, cond, return_ids=False):
+            c, c_in, info = cond
+            return self.unet(x_noisy, t_, context=c, context_in=c_in, extra_info=info)
+
+    DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)  # reference forces "cuda" (ddim.py:22-26)
+    B = 1
+    model = FakeLDM(net)
+    sampler = DDIMSampler(model)
+    x_T = torch.randn(B, 4, H, H, generator=g)
+    c = torch.randn(B * 16, 77, cfg.context_dim, generator=g)
+    uc = torch.randn(B * 16, 77, cfg.context_dim, generator=g)
+    S = 5
+    samples, _ = sampler.sample(S=S, conditioning=(c, ["p"] * B, extra_info()), batch_size=B, shape=[4, H, H],
+                                verbose=False, guidance_scale=[10.0, 4.0],
+                                unconditional_conditioning=(uc, [""] * B, extra_info()), eta=0.0, x_T=x_T)
+    golden["ddim_xT"], golden["ddim_c"], golden["ddim_uc"] = x_T.numpy(), c.numpy(), uc.numpy()
+    golden["ddim_S5_samples"] = samples.numpy()
+
+    # ---- tiny VAE decoder ----
+    vcfg = O.TINY_VAE
+    vsd = O.synth_state_dict(O.vae_param_shapes(vcfg), seed=12)
+    dec = Decoder(ch=vcfg.ch, out_ch=vcfg.out_ch, ch_mult=tuple(vcfg.ch_mult), num_res_blocks=vcfg.num_res_blocks,
+                  attn_resolutions=[], dropout=0.0, in_channels=3, resolution=256, z_channels=vcfg.z_channels,
+                  double_z=True).eval()
+    load(dec, vsd, O.VAE_PREFIX + "decoder.")
+    pq = torch.nn.Conv2d(vcfg.embed_dim, vcfg.z_channels, 1)
+    pq.weight.data.copy_(vsd[O.VAE_PREFIX + "post_quant_conv.weight"])
+    pq.bias.data.copy_(vsd[O.VAE_PREFIX + "post_quant_conv.bias"])
+    z = torch.randn(1, 4, 8, 8, generator=g) * 0.18215 * 3.0
+    img = dec(pq(z / vcfg.scale_factor))  # ddpm.py:1258 + autoencoder.py:330-333
+    golden["vae_z"] = z.numpy()
+    golden["vae_tiny_img"] = img.numpy()
+
+    np.savez_compressed(OUT / "golden_tiny.npz", **golden)
+    print("wrote", OUT / "golden_tiny.npz", {k: v.shape for k, v in list(golden.items())[:6]}, "...")
+
+    # ---- full-size SD-1.5 UNet: eps for one CFG pair + per-block checksums; full-size VAE decode ----
+    if "--full" in sys.argv:
+        full = {}
+        cfg = O.SD15_UNET
+        sd = O.synth_state_dict(O.unet_param_shapes(cfg), seed=21)
+        net = ref_unet(cfg)
+        load(net, sd, O.UNET_PREFIX)
+        nparams = sum(p.numel() for p in net.parameters())
+        assert nparams == 859_520_964, nparams
+        x = torch.randn(2, 4, 64, 64, generator=g)
+        tt = torch.tensor([981, 981])
+        ctx = torch.randn(2 * 16, 77, 768, generator=g)
+        taps = {}
+        hooks = []
+        for i, m in enumerate(net.input_blocks):
+            hooks.append(m.register_forward_hook(lambda mod, a, o, k=f"input_blocks.{i}": taps.__setitem__(k, o)))
+        hooks.append(net.middle_block.register_forward_hook(lambda mod, a, o: taps.__setitem__("middle_block", o)))
+        for i, m in enumerate(net.output_blocks):
+            hooks.append(m.register_forward_hook(lambda mod, a, o, k=f"output_blocks.{i}": taps.__setitem__(k, o)))
+        eps = net(x, tt, context=ctx, extra_info=extra_info())
+        full["sd15_x"], full["sd15_t"] = x.numpy(), tt.numpy()
+        full["sd15_ctx_seed_note"] = np.array([0])
+        full["sd15_ctx"] = ctx.numpy().astype(np.float16)  # 9.5 MB fp32 -> 4.7 MB; inputs are re-read as fp16->fp32
+        # the forward above must see the SAME rounded context the tests will feed: recompute with it
+        ctx16 = torch.tensor(full["sd15_ctx"]).float()
+        taps.clear()
+        eps = net(x, tt, context=ctx16, extra_info=extra_info())
+        for hk in hooks:
+            hk.remove()
+        full["sd15_eps"] = eps.numpy()
+        for k, v in taps.items():
+            flat = v.reshape(-1)
+            full[f"sd15_tap_{k}_stats"] = np.array([flat.mean().item(), flat.std().item()], dtype=np.float64)
+            full[f"sd15_tap_{k}_sample"] = flat[:: max(1, flat.numel() // 64)][:64].numpy()
+        del net, sd
+        vcfg = O.SD15_VAE
+        vsd = O.synth_state_dict(O.vae_param_shapes(vcfg), seed=22)
+        dec = Decoder(ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], dropout=0.0,
+                      in_channels=3, resolution=256, z_channels=4, double_z=True).eval()
+        load(dec, vsd, O.VAE_PREFIX + "decoder.")
+        assert sum(p.numel() for p in dec.parameters()) == 49_490_179
+        pq = torch.nn.Conv2d(4, 4, 1)
+        pq.weight.data.copy_(vsd[O.VAE_PREFIX + "post_quant_conv.weight"])
+        pq.bias.data.copy_(vsd[O.VAE_PREFIX + "post_quant_conv.bias"])
+        z = torch.randn(1, 4, 64, 64, generator=g) * 0.18215 * 3.0
+        img = dec(pq(z / 0.18215))
+        full["sd15_vae_z"] = z.numpy()
+        full["sd15_vae_img_crop"] = img[:, :, 192:320, 192:320].numpy()
+        full["sd15_vae_img_stats"] = np.array([img.mean().item(), img.std().item(), img.abs().max().item()])
+        full["sd15_vae_img_sub8"] = img[:, :, ::8, ::8].numpy()
+        np.savez_compressed(OUT / "golden_sd15.npz", **full)
+        print("wrote", OUT / "golden_sd15.npz")
+
+
+if __name__ == "__main__":
+    main()
