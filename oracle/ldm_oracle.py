@@ -234,9 +234,10 @@ def synth_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int) -> SD:
 # schedules
 # ----------------------------------------------------------------------------------------
 def make_beta_schedule(n_timestep: int = 1000, linear_start: float = 0.00085, linear_end: float = 0.0120) -> np.ndarray:
-    """'linear' schedule: linspace over sqrt(beta), squared, float64
-    (ldm/modules/diffusionmodules/util.py:21-25)."""
-    return np.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=np.float64) ** 2
+    """'linear' schedule: torch.linspace (float64) over sqrt(beta), squared, as numpy
+    (ldm/modules/diffusionmodules/util.py:21-25,43).  torch's linspace differs from numpy's by an
+    ulp on a quarter of the entries — the golden fixture pins the torch form."""
+    return (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2).numpy()
 
 
 def register_schedule(n_timestep=1000, linear_start=0.00085, linear_end=0.0120):

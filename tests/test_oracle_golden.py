@@ -1,0 +1,122 @@
+"""Pin the CPU oracle (oracle/ldm_oracle.py) against golden vectors produced by the REFERENCE's
+own modules (tests/golden/gen_golden.py; fixtures golden_tiny.npz / golden_sd15.npz).
+
+fp32 CPU vs fp32 CPU of the same torch build: the restatement must agree to rounding —
+tolerance 2e-5 absolute on O(1) activations (op order inside einsum/bmm may differ).
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from oracle import ldm_oracle as O  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    return dict(np.load(GOLD / "golden_tiny.npz"))
+
+
+def test_schedule_tables(tiny):
+    betas = O.make_beta_schedule()
+    np.testing.assert_array_equal(betas, tiny["sched_betas"])
+    np.testing.assert_array_equal(np.cumprod(1.0 - betas), tiny["sched_alphas_cumprod"])
+    sched = O.register_schedule()
+    for S in (10, 50):
+        ts = O.make_ddim_timesteps(S)
+        np.testing.assert_array_equal(ts, tiny[f"ddim_timesteps_S{S}"])
+        sig, a, ap = O.make_ddim_sampling_parameters(sched["alphas_cumprod"], ts, 0.0)
+        np.testing.assert_array_equal(a.numpy(), tiny[f"ddim_alphas_S{S}"])
+        np.testing.assert_array_equal(ap, tiny[f"ddim_alphas_prev_S{S}"])
+        np.testing.assert_array_equal(sig, tiny[f"ddim_sigmas_S{S}"])
+    assert list(O.make_ddim_timesteps(50)[:3]) == [1, 21, 41] and O.make_ddim_timesteps(50)[-1] == 981
+    assert list(O.make_ddim_timesteps(10)) == [1, 101, 201, 301, 401, 501, 601, 701, 801, 901]
+
+
+def test_guidance_annealing():
+    gs = O.guidance_schedule((10.0, 4.0), 50)
+    assert gs[0] == 10.0 and abs(gs[-1] - 4.0) < 1e-9 and abs(gs[1] - 9.877551020408163) < 1e-12
+
+
+def test_timestep_embedding(tiny):
+    got = O.timestep_embedding(torch.tensor(tiny["temb_t"]), 320).numpy()
+    np.testing.assert_array_equal(got, tiny["temb_320"])
+
+
+def test_param_inventory_counts():
+    n_unet = sum(int(np.prod(s)) for s in O.unet_param_shapes(O.SD15_UNET).values())
+    n_vae = sum(int(np.prod(s)) for s in O.vae_param_shapes(O.SD15_VAE).values())
+    assert n_unet == 859_520_964
+    assert len(O.unet_param_shapes(O.SD15_UNET)) == 686
+    # decoder 49,490,179 + post_quant_conv 4*4+4
+    assert n_vae == 49_490_179 + 20
+
+
+def test_tiny_unet_matches_reference(tiny):
+    sd = O.synth_state_dict(O.unet_param_shapes(O.TINY_UNET), seed=11)
+    taps = {}
+    eps = O.unet_forward(sd, O.TINY_UNET, torch.tensor(tiny["tiny_x"]), torch.tensor(tiny["tiny_t"]),
+                         torch.tensor(tiny["tiny_ctx"]), taps=taps)
+    err = np.abs(eps.numpy() - tiny["tiny_eps"]).max()
+    assert err < 2e-5, err
+    assert np.abs(tiny["tiny_eps"]).max() > 0.05  # non-vacuous (zero-init tensors were re-randomised)
+    for k, v in taps.items():
+        flat = v.reshape(-1)
+        sample = flat[:: max(1, flat.numel() // 64)][:64].numpy()
+        ref = tiny[f"tiny_tap_{k}_sample"]
+        assert np.abs(sample - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), k
+
+
+def test_tiny_ddim_matches_reference_sampler(tiny):
+    cfg = O.TINY_UNET
+    sd = O.synth_state_dict(O.unet_param_shapes(cfg), seed=11)
+    apply = lambda x, t, c: O.unet_forward(sd, cfg, x, t, c)
+    out = O.ddim_sample(apply, O.register_schedule(), 5, torch.tensor(tiny["ddim_xT"]), torch.tensor(tiny["ddim_c"]),
+                        torch.tensor(tiny["ddim_uc"]), guidance_scale=(10.0, 4.0))
+    ref = tiny["ddim_S5_samples"]  # guidance 10 on random weights: |x| reaches ~30
+    err = np.abs(out.numpy() - ref).max()
+    assert err < 1e-5 * np.abs(ref).max(), err
+
+
+def test_tiny_vae_matches_reference(tiny):
+    sd = O.synth_state_dict(O.vae_param_shapes(O.TINY_VAE), seed=12)
+    img = O.vae_decode(sd, O.TINY_VAE, torch.tensor(tiny["vae_z"]))
+    ref = tiny["vae_tiny_img"]
+    assert img.shape == ref.shape
+    err = np.abs(img.numpy() - ref).max()
+    assert err < 2e-5 * max(1.0, np.abs(ref).max()), err
+
+
+@pytest.mark.skipif(not (GOLD / "golden_sd15.npz").exists(), reason="full-size fixture not generated")
+def test_sd15_unet_matches_reference():
+    """Full SD-1.5 UNet (859.5 M params), one CFG pair at 64x64: ~25 s of CPU."""
+    g = dict(np.load(GOLD / "golden_sd15.npz"))
+    sd = O.synth_state_dict(O.unet_param_shapes(O.SD15_UNET), seed=21)
+    taps = {}
+    eps = O.unet_forward(sd, O.SD15_UNET, torch.tensor(g["sd15_x"]), torch.tensor(g["sd15_t"]),
+                         torch.tensor(g["sd15_ctx"]).float(), taps=taps)
+    ref = g["sd15_eps"]
+    err = np.abs(eps.numpy() - ref).max()
+    assert err < 5e-5 * max(1.0, np.abs(ref).max()), err
+    for k, v in taps.items():
+        flat = v.reshape(-1)
+        sample = flat[:: max(1, flat.numel() // 64)][:64].numpy()
+        r = g[f"sd15_tap_{k}_sample"]
+        assert np.abs(sample - r).max() < 5e-5 * max(1.0, np.abs(r).max()), k
+
+
+@pytest.mark.skipif(not (GOLD / "golden_sd15.npz").exists(), reason="full-size fixture not generated")
+def test_sd15_vae_matches_reference():
+    g = dict(np.load(GOLD / "golden_sd15.npz"))
+    sd = O.synth_state_dict(O.vae_param_shapes(O.SD15_VAE), seed=22)
+    img = O.vae_decode(sd, O.SD15_VAE, torch.tensor(g["sd15_vae_z"]))
+    crop = img[:, :, 192:320, 192:320].numpy()
+    scale = max(1.0, float(g["sd15_vae_img_stats"][2]))
+    assert np.abs(crop - g["sd15_vae_img_crop"]).max() < 5e-5 * scale
+    assert np.abs(img[:, :, ::8, ::8].numpy() - g["sd15_vae_img_sub8"]).max() < 5e-5 * scale
