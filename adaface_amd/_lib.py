@@ -49,6 +49,7 @@ _SIGS = [
     ("af_create", C.c_int, [C.c_int, C.POINTER(AfConfig), C.POINTER(_P)]),
     ("af_destroy", None, [_P]),
     ("af_load_tensor", C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64)]),
+    ("af_load_tensor_device", C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64)]),
     ("af_num_tensors", C.c_int, [_P]),
     ("af_tensor_name", C.c_char_p, [_P, C.c_int]),
     ("af_tensor_loaded", C.c_int, [_P, C.c_int]),
@@ -60,6 +61,10 @@ _SIGS = [
     ("af_vae_decode", C.c_int, [_P, _P, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("af_to_uint8", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("af_arena_bytes", C.c_int64, [_P]),
+    ("af_prof_enable", C.c_int, [C.c_int]),
+    ("af_prof_reset", C.c_int, []),
+    ("af_prof_collect", C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double)]),
     ("af_op_conv2d", C.c_int, [C.c_int, _P, _P, _P, _P, _P] + [C.c_int] * 9 + [_P]),
     ("af_op_linear", C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     ("af_op_groupnorm", C.c_int, [C.c_int, _P, _P, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -218,6 +218,8 @@ template <typename T> int af_launch_attention(const AttnParams& p, int B, int dh
     return -1;
   }
   if (p.Nq <= 0 || B <= 0) return 0;
+  AfProfScope prof(AF_K_ATTENTION, stream, 4.0 * B * p.H * (double)p.Nq * p.Nk * dh,
+                   (2.0 * p.Nq + 2.0 * p.Nk) * B * p.H * dh * sizeof(T));
   switch (dh) {
     case 8: return launch_attn<T, 8>(p, B, stream);
     case 16: return launch_attn<T, 16>(p, B, stream);

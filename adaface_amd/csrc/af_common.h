@@ -27,6 +27,22 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 void af_set_error_msg(const char* fmt, ...);
 
+// per-kernel-class HIP-event profiling (enabled only by bench.py; see af_prof_* in adaface_hip.h)
+enum { AF_K_CONV_GEMM = 0, AF_K_ATTENTION = 1, AF_K_GROUPNORM = 2, AF_K_LAYERNORM = 3, AF_K_OTHER = 4, AF_K_COUNT = 5 };
+extern int g_af_prof_enabled;
+void af_prof_begin_impl(int cls, hipStream_t s, double flops, double bytes);
+void af_prof_end_impl(hipStream_t s);
+struct AfProfScope {
+  hipStream_t s;
+  bool on;
+  AfProfScope(int cls, hipStream_t s_, double flops, double bytes) : s(s_), on(((g_af_prof_enabled >> cls) & 1) != 0) {
+    if (on) af_prof_begin_impl(cls, s, flops, bytes);
+  }
+  ~AfProfScope() {
+    if (on) af_prof_end_impl(s);
+  }
+};
+
 // ---------------------------------------------------------------------------
 // scalar conversion helpers
 // ---------------------------------------------------------------------------
@@ -125,6 +141,7 @@ struct ConvGemmParams {
   int ldw;                // elements between weight rows (>= K)
   int Wrows;              // rows that may be read (padded rows are zero)
   int M, N, K;            // N = valid GEMM columns (multiple of 4)
+  int k_logical;          // un-padded K for algorithmic FLOP accounting (0 = K)
   const float* bias;      // [N] or null
   const void* rowbias;    // T, [B][ldrb] per-sample bias (time embedding) or null
   int ldrb;

@@ -268,6 +268,8 @@ template <typename T> int af_launch_conv_gemm(const ConvGemmParams& p, int batch
     return -1;
   }
   if (p.M <= 0 || p.N <= 0) return 0;
+  AfProfScope prof(AF_K_CONV_GEMM, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K) * batch,
+                   ((double)p.M * p.K / (p.ks * p.ks) + (double)p.N * p.K + (double)p.M * p.N) * batch * sizeof(T));
   const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
   if (p.epilogue == AF_EPI_GEGLU) {
     if (p.N % 64 != 0) { af_set_error_msg("conv_gemm: GEGLU needs N%%64==0"); return -1; }

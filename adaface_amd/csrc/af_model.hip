@@ -37,6 +37,40 @@ void af_set_error_msg(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+// ----------------------------------------------------------------------------
+// HIP-event profiling per kernel class (bench.py's roofline leg)
+// ----------------------------------------------------------------------------
+int g_af_prof_enabled = 0;
+namespace {
+struct ProfRec {
+  hipEvent_t start, stop;
+  int cls;
+  double flops, bytes;
+};
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+size_t g_prof_pool_used = 0;
+hipEvent_t prof_event() {
+  if (g_prof_pool_used == g_prof_pool.size()) {
+    hipEvent_t e;
+    hipEventCreate(&e);
+    g_prof_pool.push_back(e);
+  }
+  return g_prof_pool[g_prof_pool_used++];
+}
+}  // namespace
+void af_prof_begin_impl(int cls, hipStream_t s, double flops, double bytes) {
+  ProfRec r;
+  r.start = prof_event();
+  r.stop = prof_event();
+  r.cls = cls;
+  r.flops = flops;
+  r.bytes = bytes;
+  hipEventRecord(r.start, s);
+  g_prof_recs.push_back(r);
+}
+void af_prof_end_impl(hipStream_t s) { hipEventRecord(g_prof_recs.back().stop, s); }
+
 #define AF_TRY(expr)            \
   do {                          \
     int _rc = (expr);           \
@@ -471,8 +505,8 @@ static int build_vae(Builder& b) {
   const std::string P = "first_stage_model.";
   const int nres = c.n_vae_ch_mult;
   int block_in = c.vae_ch * c.vae_ch_mult[nres - 1];
-  if (c.vae_ch % bk_of(h->dtype) != 0 && c.vae_ch % 32 != 0) {
-    af_set_error_msg("vae: ch must be a multiple of 32");
+  if (c.vae_ch % bk_of(h->dtype) != 0) {
+    af_set_error_msg("vae: ch (%d) must be a multiple of %d", c.vae_ch, bk_of(h->dtype));
     return AF_ERR_INVALID;
   }
   b.make_conv(h->post_quant, P + "post_quant_conv", c.vae_embed_dim, c.vae_z_channels, 1, true, true, true);
@@ -560,6 +594,7 @@ struct Runner {
     p.M = (int)out.npix();
     p.N = n_valid > 0 ? n_valid : round_up(L.cout, 4);
     p.K = L.ldw;
+    p.k_logical = L.ks * L.ks * L.cin;
     p.bias = L.bias;
     p.rowbias = rowbias; p.ldrb = ldrb;
     p.residual = residual ? residual->p : nullptr;
@@ -969,7 +1004,16 @@ int af_tensor_shape(af_handle* h, int i, int64_t* shape4) {
   return (int)s.shape.size();
 }
 
+static int load_tensor_impl(af_handle* h, const char* name, const float* data, int ndim, const int64_t* shape,
+                            bool on_device);
 int af_load_tensor(af_handle* h, const char* name, const float* host_data, int ndim, const int64_t* shape) {
+  return load_tensor_impl(h, name, host_data, ndim, shape, false);
+}
+int af_load_tensor_device(af_handle* h, const char* name, const float* dev_data, int ndim, const int64_t* shape) {
+  return load_tensor_impl(h, name, dev_data, ndim, shape, true);
+}
+static int load_tensor_impl(af_handle* h, const char* name, const float* host_data, int ndim, const int64_t* shape,
+                            bool on_device) {
   if (!h || !name || !host_data) { af_set_error_msg("af_load_tensor: null argument"); return AF_ERR_INVALID; }
   auto it = h->slots.find(name);
   if (it == h->slots.end()) { af_set_error_msg("af_load_tensor: unknown tensor '%s'", name); return AF_ERR_NAME; }
@@ -987,7 +1031,10 @@ int af_load_tensor(af_handle* h, const char* name, const float* host_data, int n
   }
   HIP_CHECK_RET(hipSetDevice(h->device));
   const size_t bytes = (size_t)n * sizeof(float);
-  if (bytes > h->stage_bytes) {
+  const float* srcp = host_data;
+  if (on_device) {
+    HIP_CHECK_RET(hipDeviceSynchronize());  // the caller's producer stream may differ from ours
+  } else if (bytes > h->stage_bytes) {
     if (h->stage) hipFree(h->stage);
     h->stage = nullptr;
     h->stage_bytes = 0;
@@ -996,13 +1043,16 @@ int af_load_tensor(af_handle* h, const char* name, const float* host_data, int n
     h->stage = reinterpret_cast<float*>(p);
     h->stage_bytes = bytes;
   }
-  HIP_CHECK_RET(hipMemcpy(h->stage, host_data, bytes, hipMemcpyHostToDevice));
+  if (!on_device) {
+    HIP_CHECK_RET(hipMemcpy(h->stage, host_data, bytes, hipMemcpyHostToDevice));
+    srcp = h->stage;
+  }
   if (s.kind == Slot::WEIGHT) {
     AF_TRY(DISPATCH(h->dtype,
-                    af_launch_repack_weight<bf16>(h->stage, s.dst, s.rows, s.cin, s.cin_pad, s.ks, s.ldw, s.row_off, s.perm, 0),
-                    af_launch_repack_weight<float>(h->stage, s.dst, s.rows, s.cin, s.cin_pad, s.ks, s.ldw, s.row_off, s.perm, 0)));
+                    af_launch_repack_weight<bf16>(srcp, s.dst, s.rows, s.cin, s.cin_pad, s.ks, s.ldw, s.row_off, s.perm, 0),
+                    af_launch_repack_weight<float>(srcp, s.dst, s.rows, s.cin, s.cin_pad, s.ks, s.ldw, s.row_off, s.perm, 0)));
   } else {
-    AF_TRY(af_launch_permute_bias(h->stage, s.dst_f, s.rows, s.perm, 0));
+    AF_TRY(af_launch_permute_bias(srcp, s.dst_f, s.rows, s.perm, 0));
   }
   HIP_CHECK_RET(hipStreamSynchronize(0));
   s.loaded = true;
@@ -1120,5 +1170,30 @@ int af_to_uint8(const float* img_dev, uint8_t* u8_dev, int B, int H, int W, void
 }
 
 int64_t af_arena_bytes(af_handle* h) { return h ? (int64_t)h->arena.cap : 0; }
+
+int af_prof_enable(int class_mask) {
+  g_af_prof_enabled = class_mask;
+  return 0;
+}
+int af_prof_reset(void) {
+  g_prof_recs.clear();
+  g_prof_pool_used = 0;
+  return 0;
+}
+int af_prof_collect(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes) {
+  for (int c = 0; c < n_classes; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; bytes[c] = 0; }
+  for (auto& r : g_prof_recs) {
+    HIP_CHECK_RET(hipEventSynchronize(r.stop));
+    float t = 0.f;
+    HIP_CHECK_RET(hipEventElapsedTime(&t, r.start, r.stop));
+    if (r.cls < n_classes) {
+      ms[r.cls] += t;
+      launches[r.cls] += 1;
+      flops[r.cls] += r.flops;
+      bytes[r.cls] += r.bytes;
+    }
+  }
+  return 0;
+}
 
 }  // extern "C"

@@ -36,12 +36,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
   const T* xb = x + (long)b * batch_stride;
 
   if (NV <= 256) {
-    const int PL = 256 / NV;  // pixel lanes
+    // PL pixel lanes x NV vector columns; per-lane partials go to LDS slots and are summed in a
+    // fixed order (no atomics: results are bitwise reproducible run to run)
+    const int PL = 256 / NV;
     const int v = tid % NV, pl = tid / NV;
-    if (pl < PL) {
-      float a[EPC], q[EPC];
+    float a[EPC], q[EPC];
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) { a[e] = 0.f; q[e] = 0.f; }
+    for (int e = 0; e < EPC; ++e) { a[e] = 0.f; q[e] = 0.f; }
+    if (pl < PL) {
       for (int pix = p0 + pl; pix < p1; pix += PL) {
         Vec16<T> vv;
         vv.u = *reinterpret_cast<const uint4*>(xb + (long)pix * ldc + v * EPC);
@@ -52,11 +54,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
           q[e] += f * f;
         }
       }
+    }
+    for (int lane_p = 0; lane_p < PL; ++lane_p) {
+      if (pl == lane_p) {
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        atomicAdd(&s_sum[v * EPC + e], a[e]);
-        atomicAdd(&s_sq[v * EPC + e], q[e]);
+        for (int e = 0; e < EPC; ++e) {
+          s_sum[v * EPC + e] += a[e];
+          s_sq[v * EPC + e] += q[e];
+        }
       }
+      __syncthreads();
     }
   } else {
     for (int v = tid; v < NV; v += 256) {
@@ -247,6 +254,7 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
   }
   int P;
   const int nchunk = af_gn_chunking(HW, &P);
+  AfProfScope prof(AF_K_GROUPNORM, stream, 0.0, 2.0 * B * HW * (double)Cn * sizeof(T));
   float* partial = reinterpret_cast<float*>(workspace);
   float* stats = partial + (size_t)B * nchunk * GN_GROUPS * 2;
   hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nchunk, B), dim3(256), 0, stream,
@@ -269,6 +277,7 @@ int af_launch_layernorm(const void* x, int ldx, long rows, int Cn, const float* 
     return -1;
   }
   if (rows <= 0) return 0;
+  AfProfScope prof(AF_K_LAYERNORM, stream, 0.0, 2.0 * rows * (double)Cn * sizeof(T));
   hipLaunchKernelGGL((layernorm_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream,
                      reinterpret_cast<const T*>(x), ldx, rows, Cn, gamma, beta, eps,
                      reinterpret_cast<T*>(y), ldy);

@@ -1,0 +1,154 @@
+"""Engine: Python owner of one af_handle (include/adaface_hip.h).
+
+One Engine = the HIP-side twin of one reference nn.Module (a UNetModel or an
+AutoencoderKL decoder): repacked weights + activation arena living in HBM, driven on the
+current torch HIP stream.  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import AfConfig, DTYPES, check, ptr, stream_ptr
+
+UNET_PREFIX = "model.diffusion_model."
+VAE_PREFIX = "first_stage_model."
+
+
+def _fill(arr, values: Sequence[int]):
+    if len(values) > 8:
+        raise ValueError("at most 8 entries supported")
+    for i, v in enumerate(values):
+        arr[i] = int(v)
+
+
+class Engine:
+    def __init__(self, *, dtype: str = "bf16", device: int = 0, unet: Optional[dict] = None, vae: Optional[dict] = None):
+        """unet: UNetModel ctor kwargs (in_channels, model_channels, out_channels, num_res_blocks,
+        attention_resolutions, channel_mult, num_heads, context_dim, transformer_depth);
+        vae: Decoder ddconfig (ch, out_ch, ch_mult, num_res_blocks, z_channels) + embed_dim."""
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        if not torch.cuda.is_available():
+            raise _lib.AfError("adaface_amd.Engine needs a HIP device (there is no CPU path)")
+        cfg = AfConfig()
+        cfg.dtype = DTYPES[dtype]
+        self.dtype = dtype
+        self.device = torch.device("cuda", device)
+        if unet is not None:
+            cfg.build_unet = 1
+            cfg.in_channels = unet["in_channels"]
+            cfg.model_channels = unet["model_channels"]
+            cfg.out_channels = unet["out_channels"]
+            cfg.num_res_blocks = unet["num_res_blocks"]
+            ar = list(unet["attention_resolutions"])
+            cm = list(unet["channel_mult"])
+            cfg.n_attention_resolutions = len(ar)
+            _fill(cfg.attention_resolutions, ar)
+            cfg.n_channel_mult = len(cm)
+            _fill(cfg.channel_mult, cm)
+            cfg.num_heads = unet["num_heads"]
+            cfg.context_dim = unet["context_dim"]
+            cfg.transformer_depth = unet.get("transformer_depth", 1)
+            cfg.n_context_layers = unet.get("n_context_layers", 16)
+        if vae is not None:
+            cfg.build_vae = 1
+            cfg.vae_ch = vae["ch"]
+            cfg.vae_out_ch = vae["out_ch"]
+            cfg.vae_num_res_blocks = vae["num_res_blocks"]
+            cfg.vae_z_channels = vae["z_channels"]
+            cfg.vae_embed_dim = vae.get("embed_dim", vae["z_channels"])
+            vm = list(vae["ch_mult"])
+            cfg.n_vae_ch_mult = len(vm)
+            _fill(cfg.vae_ch_mult, vm)
+        self.unet_cfg, self.vae_cfg = unet, vae
+        torch.cuda.init()
+        check(self._lib.af_create(device, C.byref(cfg), C.byref(self._h)), "af_create")
+        self._ctx_key = None
+
+    # -- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.af_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights --------------------------------------------------------------------------
+    def tensor_table(self) -> Dict[str, tuple]:
+        """name -> expected shape, as the C library derived it."""
+        n = self._lib.af_num_tensors(self._h)
+        out = {}
+        buf = (C.c_int64 * 4)()
+        for i in range(n):
+            name = self._lib.af_tensor_name(self._h, i).decode()
+            nd = self._lib.af_tensor_shape(self._h, i, buf)
+            out[name] = tuple(int(buf[d]) for d in range(nd))
+        return out
+
+    def missing_tensors(self):
+        n = self._lib.af_num_tensors(self._h)
+        return [self._lib.af_tensor_name(self._h, i).decode() for i in range(n)
+                if not self._lib.af_tensor_loaded(self._h, i)]
+
+    def load_tensor(self, name: str, t: torch.Tensor):
+        t = t.detach().to(torch.float32).contiguous()
+        shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
+        fn = self._lib.af_load_tensor_device if t.is_cuda else self._lib.af_load_tensor
+        check(fn(self._h, name.encode(), C.c_void_p(t.data_ptr()), t.dim(), shape), f"af_load_tensor({name})")
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "", strict: bool = True):
+        """Feed every tensor the library expects from `sd` (keys = `prefix` + library name)."""
+        table = self.tensor_table()
+        for name in table:
+            key = name if not prefix else name  # library names already carry the checkpoint prefix
+            if key in sd:
+                self.load_tensor(name, sd[key])
+        missing = self.missing_tensors()
+        if strict and missing:
+            raise KeyError(f"{len(missing)} tensors missing from state_dict, e.g. {missing[:5]}")
+        return missing
+
+    # -- hot path -------------------------------------------------------------------------
+    def set_context(self, ctx: torch.Tensor, Bf: int, layerwise: bool):
+        """ctx: fp32 device tensor [Bf*16, T, D] (layerwise) or [Bf, T, D]."""
+        if not ctx.is_cuda:
+            raise ValueError("context must be a device tensor")
+        ctx = ctx.contiguous().float()
+        n_tokens = ctx.shape[1]
+        L = self.unet_cfg.get("n_context_layers", 16) if layerwise else 1
+        if ctx.shape[0] != Bf * L or ctx.shape[2] != self.unet_cfg["context_dim"]:
+            raise ValueError(f"context shape {tuple(ctx.shape)} does not match batch {Bf} x layers {L}")
+        check(self._lib.af_set_context(self._h, ptr(ctx), Bf, n_tokens, 1 if layerwise else 0, stream_ptr()),
+              "af_set_context")
+
+    def unet_forward(self, x: torch.Tensor, t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = x.contiguous().float()
+        t = t.contiguous().long()
+        Bf, _, H, W = x.shape
+        if out is None:
+            out = torch.empty(Bf, self.unet_cfg["out_channels"], H, W, device=x.device, dtype=torch.float32)
+        check(self._lib.af_unet_forward(self._h, ptr(x), ptr(t), ptr(out), Bf, H, W, stream_ptr()), "af_unet_forward")
+        return out
+
+    def vae_decode(self, z: torch.Tensor, scale_factor: float = 1.0, want_uint8: bool = False, want_float: bool = True):
+        z = z.contiguous().float()
+        B, _, H, W = z.shape
+        f = 2 ** (len(self.vae_cfg["ch_mult"]) - 1)
+        img = torch.empty(B, self.vae_cfg["out_ch"], H * f, W * f, device=z.device, dtype=torch.float32) if want_float else None
+        u8 = torch.empty(B, H * f, W * f, 3, device=z.device, dtype=torch.uint8) if want_uint8 else None
+        check(self._lib.af_vae_decode(self._h, ptr(z), float(scale_factor), ptr(img), ptr(u8), B, H, W, stream_ptr()),
+              "af_vae_decode")
+        if want_float and want_uint8:
+            return img, u8
+        return u8 if want_uint8 else img
+
+    def arena_bytes(self) -> int:
+        return int(self._lib.af_arena_bytes(self._h))

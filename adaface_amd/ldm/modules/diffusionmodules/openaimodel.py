@@ -1,0 +1,107 @@
+"""Drop-in for ldm.modules.diffusionmodules.openaimodel.UNetModel (reference
+openaimodel.py:417-1052): same constructor kwargs, same forward signature, same state_dict
+keys; the forward pass is one af_unet_forward call into the hand-written HIP path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from adaface_amd import layout
+from adaface_amd.ldm._hipmodule import HipModule, build_param_tree
+
+
+class UNetModel(HipModule):
+    _ckpt_prefix = "model.diffusion_model."
+
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None,
+                 use_checkpoint=False, use_fp16=False, num_heads=-1, num_head_channels=-1, num_heads_upsample=-1,
+                 use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=False,
+                 use_spatial_transformer=False, transformer_depth=1, context_dim=None, n_embed=None, legacy=True):
+        super().__init__()
+        # the SD-v1 family is the hot path (v1-inference-ada.yaml:35-50); other branches of the
+        # reference constructor are training / legacy-LDM variants outside SURVEY.md §8
+        unsupported = {
+            "dims != 2": dims != 2, "num_classes": num_classes is not None, "use_scale_shift_norm": use_scale_shift_norm,
+            "resblock_updown": resblock_updown, "n_embed": n_embed is not None, "dropout": dropout != 0,
+            "not conv_resample": not conv_resample, "not use_spatial_transformer": not use_spatial_transformer,
+            "num_head_channels": num_head_channels != -1,
+            "num_heads_upsample": num_heads_upsample not in (-1, num_heads),
+        }
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f"UNetModel: options outside the SD-v1 denoising path: {bad}")
+        if context_dim is None or num_heads == -1:
+            raise ValueError("UNetModel: context_dim and num_heads are required (spatial transformer)")
+        if hasattr(context_dim, "__len__"):
+            context_dim = list(context_dim)
+            if len(context_dim) != 1:
+                raise NotImplementedError("a single context_dim is supported")
+            context_dim = context_dim[0]
+        self.image_size = image_size
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = tuple(attention_resolutions)
+        self.channel_mult = tuple(channel_mult)
+        self.num_heads = num_heads
+        self.context_dim = int(context_dim)
+        self.transformer_depth = transformer_depth
+        self.use_checkpoint = use_checkpoint  # accepted, meaningless at inference (util.py:115)
+        self.dtype = torch.float32            # dtype of the tensors crossing the boundary
+        self.debug_attn = False
+        if use_fp16:
+            self.compute_dtype = "bf16"
+        shapes = layout.unet_param_shapes(**self._layout_kwargs())
+        build_param_tree(self, shapes, zero_init=layout.unet_zero_init_names(shapes))
+        object.__setattr__(self, "_ctx_key", None)
+
+    def _layout_kwargs(self):
+        return dict(in_channels=self.in_channels, model_channels=self.model_channels, out_channels=self.out_channels,
+                    num_res_blocks=self.num_res_blocks, attention_resolutions=self.attention_resolutions,
+                    channel_mult=self.channel_mult, context_dim=self.context_dim,
+                    transformer_depth=self.transformer_depth)
+
+    def _engine_kwargs(self):
+        kw = self._layout_kwargs()
+        kw.update(num_heads=self.num_heads, n_context_layers=16)
+        return {"unet": kw}
+
+    def _mark_dirty(self):
+        super()._mark_dirty()
+        object.__setattr__(self, "_ctx_key", None)  # cached K/V depend on the weights
+
+    @torch.no_grad()
+    def forward(self, x, timesteps=None, context=None, y=None, context_in=None, extra_info=None, **kwargs):
+        """x [B,C,H,W], timesteps [B], context [B*16,T,D] (layerwise) or [B,T,D]; returns eps [B,C,H,W] fp32.
+        Mirrors openaimodel.py:827-1052 for inference: `extra_info` keys read at :849-859."""
+        if y is not None:
+            raise NotImplementedError("class-conditional UNet (num_classes) is not on the path")
+        if timesteps is None or context is None:
+            raise ValueError("UNetModel.forward needs timesteps and context")
+        info = extra_info if extra_info is not None else {}
+        layerwise = bool(info.get("use_layerwise_context", False))
+        ks = info.get("use_conv_attn_kernel_size", None)
+        if ks is not None and ks > 0 and info.get("placeholder2indices", None) is not None:
+            raise NotImplementedError("conv-attention row replacement (attention.py:208-216) is a 'next' row "
+                                      "(SURVEY.md §8f-1), not yet built")
+        if info.get("apply_compel_cfg_prob", 0) > 0:
+            raise NotImplementedError("compel-cfg context re-weighting (openaimodel.py:898-916) is a 'next' row")
+        if info.get("img_mask", None) is not None or info.get("capture_distill_attn", False):
+            raise NotImplementedError("img_mask / capture_distill_attn are training-time options")
+        if info.get("iter_type", "normal_recon") == "mix_hijk":
+            raise NotImplementedError("iter_type 'mix_hijk' (separate k/v contexts) is a training-time option")
+        eng = self.engine(x.device)
+        B = x.shape[0]
+        key = (context.data_ptr(), getattr(context, "_version", 0), tuple(context.shape), layerwise, B)
+        if key != self._ctx_key:
+            eng.set_context(context.to(x.device), B, layerwise)
+            object.__setattr__(self, "_ctx_key", key)
+        out = eng.unet_forward(x, timesteps.to(x.device))
+        if extra_info is not None:
+            # the reference writes the (here empty) distillation capture into the caller's dict (:1031-1035)
+            extra_info["ca_layers_activations"] = {k: {} for k in ("outfeat", "attn", "attnscore", "q")}
+        return out.type(x.dtype) if x.dtype != torch.float32 else out

@@ -61,6 +61,8 @@ void af_destroy(af_handle* h);
 /* model.load_state_dict (ldm/util.py:129): one call per state_dict entry, fp32 HOST data.
  * `name` is the checkpoint key: "model.diffusion_model.<k>" or "first_stage_model.<k>". */
 int af_load_tensor(af_handle* h, const char* name, const float* host_data, int ndim, const int64_t* shape);
+/* same, from fp32 DEVICE data (synthetic weights generated on the GPU; no host round trip) */
+int af_load_tensor_device(af_handle* h, const char* name, const float* dev_data, int ndim, const int64_t* shape);
 int af_num_tensors(af_handle* h);
 const char* af_tensor_name(af_handle* h, int i);
 int af_tensor_loaded(af_handle* h, int i);
@@ -95,6 +97,14 @@ int af_to_uint8(const float* img_dev, uint8_t* u8_dev, int B, int H, int W, void
 
 /* bytes of the activation arena currently reserved by the handle (diagnostics) */
 int64_t af_arena_bytes(af_handle* h);
+
+/* ---- per-kernel-class HIP-event timing (bench.py roofline leg) ----
+ * classes: 0 conv_gemm (implicit-GEMM conv/linear), 1 attention, 2 groupnorm, 3 layernorm, 4 other.
+ * While enabled every launch of a class is bracketed by hipEventRecord on ITS stream; af_prof_collect
+ * sums elapsed ms, launch counts and the ALGORITHMIC flops / bytes of those launches per class. */
+int af_prof_enable(int class_mask); /* bit c set = time class c; 0 = off */
+int af_prof_reset(void);
+int af_prof_collect(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes);
 
 /* ---- operator-level entry points (parity tests; reference layouts, fp32 device tensors) ----
  * Each converts to the internal NHWC `dtype` layout, runs the same kernel the model

@@ -62,7 +62,7 @@ SD15_UNET = UNetConfig()
 SD15_VAE = VAEConfig()
 # structurally identical to SD-1.5 (same block / cross-attention layer layout), 5x narrower
 TINY_UNET = UNetConfig(model_channels=64, num_heads=2, context_dim=64)
-TINY_VAE = VAEConfig(ch=32, ch_mult=(1, 2, 2, 2))
+TINY_VAE = VAEConfig(ch=64, ch_mult=(1, 2, 2, 2))
 
 
 # ----------------------------------------------------------------------------------------
