@@ -72,7 +72,8 @@ def cpu_baseline(ddim_steps):
     """Oracle (CPU restatement of the reference, oracle/ldm_oracle.py) on the host cores: one UNet forward at
     CFG batch 2 (= 1/ddim_steps of one image's denoising) + one VAE decode, extrapolated to images/sec."""
     from oracle import ldm_oracle as O
-    cores = os.cpu_count() or 1
+    # one GPU's share of the host is 16 cores; more threads than that oversubscribes the box
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(7)
     sd = O.synth_state_dict(O.unet_param_shapes(O.SD15_UNET), seed=21)
