@@ -153,6 +153,15 @@ struct ConvGemmParams {
   float alpha;            // scale applied to the accumulator before bias
   // batched GEMM (blockIdx.z): element strides
   long bs_src, bs_w, bs_out, bs_res;
+  // split-K (set by the launcher): K slices write fp32 slabs ws[splitk][M][N]
+  int splitk;
+  void* ws;
+};
+
+struct AfGemmPlan {
+  int tile;         // 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64
+  int splitk;       // >= 1
+  size_t ws_bytes;  // fp32 slab workspace needed when splitk > 1
 };
 
 struct AttnParams {

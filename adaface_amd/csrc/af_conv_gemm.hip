@@ -15,27 +15,84 @@
 //   * 256 threads = 4 waves as 2(M) x 2(N); each wave owns (BM/2)x(BN/2) of the
 //     tile as 32x32 MFMA blocks.  The WEIGHT tile is the MFMA A operand and the
 //     ACTIVATION tile the B operand, so the accumulator has the output pixel on
-//     the lane and 4 consecutive output channels in consecutive registers ->
-//     8/16-byte epilogue stores and vector bias/residual loads.
+//     the lane and 4 consecutive output channels in consecutive registers.
 //   * LDS tiles are [rows][128 B] with a 16-byte-chunk XOR swizzle
 //     chunk ^= (row>>1)&7, conflict-free for ds_read_b128's 16-lane groups.
 //   * register-staged double buffering: tile k+1's global loads are issued before
 //     tile k's MFMAs and written to the other LDS buffer after them; one barrier
 //     per K tile.
+//   * epilogue through LDS: the fp32 accumulator tile is transposed in LDS so that
+//     every lane then handles 8 consecutive output channels of one pixel: bias /
+//     time-embedding / residual are read and the output written as whole 16-byte
+//     vectors, a wave covering full contiguous rows (the per-lane 8-byte scattered
+//     stores this replaces were 2-3x slower on the K<=640 linears).
+//   * 1-D grid with a bijective XCD-aware remap: the N tiles that share one
+//     activation tile are adjacent on one XCD, so the tile is fetched into that
+//     XCD's L2 once; weights (<= a few MB) stay L2-resident everywhere.
+//   * split-K (deep-K, small-M layers at 8x8 / 16x16): K slices write fp32 slabs,
+//     a second kernel reduces them and applies the epilogue.
 //   * fused epilogues: alpha, bias, per-sample time-embedding bias, residual add,
 //     GEGLU (value*gelu(gate) with value/gate rows interleaved in 32-row groups).
-#include "af_common.h"
+#include "af_kernels.h"
+
+#include <cstdlib>
+#include <cstring>
 
 template <int BM, int BN> struct TileCfg {
   static constexpr int XR = BM / 32, WR = BN / 32;
   static constexpr int WM = BM / 2, WN = BN / 2;
   static constexpr int MI = WM / 32, NI = WN / 32;
   static constexpr int TILE_BYTES = (BM + BN) * 128;
-  static constexpr int LDS_BYTES = 2 * TILE_BYTES;
+  static constexpr int EPI_LD = BN + 4;  // floats; +4 keeps float4 alignment and spreads rows over banks
+  static constexpr int EPI_BYTES = BM * EPI_LD * 4;
+  static constexpr int LDS_BYTES = (2 * TILE_BYTES > EPI_BYTES) ? 2 * TILE_BYTES : EPI_BYTES;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+// 8 consecutive outputs of one row: bias / rowbias / residual / store as 16-byte vectors
+template <typename T>
+__device__ __forceinline__ void epi_store8(const ConvGemmParams& p, float (&v)[8], int m, int b, int n, int nvalid,
+                                           T* __restrict__ out, const T* __restrict__ res,
+                                           const T* __restrict__ rowb, const float* __restrict__ bias) {
+  if (bias) {
+#pragma unroll
+    for (int hq = 0; hq < 2; ++hq)
+      if (4 * hq < nvalid) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + n + 4 * hq);
+        v[4 * hq + 0] += bv.x; v[4 * hq + 1] += bv.y; v[4 * hq + 2] += bv.z; v[4 * hq + 3] += bv.w;
+      }
+  }
+  if (rowb) {
+#pragma unroll
+    for (int hq = 0; hq < 2; ++hq)
+      if (4 * hq < nvalid) {
+        Quad<T> rb;
+        rb.load(rowb + (long)b * p.ldrb + n + 4 * hq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * hq + e] += to_f32<T>(rb.e[e]);
+      }
+  }
+  if (res) {
+#pragma unroll
+    for (int hq = 0; hq < 2; ++hq)
+      if (4 * hq < nvalid) {
+        Quad<T> rv;
+        rv.load(res + (long)m * p.ldr + n + 4 * hq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * hq + e] += to_f32<T>(rv.e[e]);
+      }
+  }
+#pragma unroll
+  for (int hq = 0; hq < 2; ++hq)
+    if (4 * hq < nvalid) {
+      Quad<T> o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o.e[e] = from_f32<T>(v[4 * hq + e]);
+      o.store(out + (long)m * p.ldo + n + 4 * hq);
+    }
 }
 
 template <typename T, int BM, int BN>
@@ -51,11 +108,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   const int lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int wm = wave & 1, wn = wave >> 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const long z = blockIdx.z;
 
-  const T* __restrict__ src = reinterpret_cast<const T*>(p.src) + z * p.bs_src;
-  const T* __restrict__ Wt = reinterpret_cast<const T*>(p.W) + z * p.bs_w;
+  // ---- block -> tile: bijective XCD-aware remap, N tiles fastest ----
+  const int ntn = (p.N + BN - 1) / BN;
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int tm = wg / ntn, tn = wg - tm * ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const long z = blockIdx.z;
+  const long zb = p.splitk > 1 ? 0 : z;   // batch index
+  const int zk = p.splitk > 1 ? (int)z : 0;  // K slice
+
+  const T* __restrict__ src = reinterpret_cast<const T*>(p.src) + zb * p.bs_src;
+  const T* __restrict__ Wt = reinterpret_cast<const T*>(p.W) + zb * p.bs_w;
 
   const int chunk = tid & 7, r0 = tid >> 3;
   const int HoWo = p.Ho * p.Wo;
@@ -87,8 +156,22 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     w_ptr[i] = Wt + (long)(w_ok[i] ? n : 0) * p.ldw + chunk * EPC;
   }
 
+  // K range of this block
+  const int KT_all = p.K / BK;
+  const int kt_per = (KT_all + p.splitk - 1) / p.splitk;
+  const int kt_begin = zk * kt_per;
+  const int kt_end = min(KT_all, kt_begin + kt_per);
+  const int KT = kt_end - kt_begin;
+
   uint4 xr[XR], wr[WR];
-  int ky = 0, kx = 0, c0 = 0;  // filter tap and channel offset of the NEXT tile to load
+  int ky, kx, c0;  // filter tap and channel offset of the NEXT tile to load
+  {
+    const int k0 = kt_begin * BK;
+    const int tap = k0 / p.Cin;
+    c0 = k0 - tap * p.Cin;
+    ky = tap / p.ks;
+    kx = tap - ky * p.ks;
+  }
 
   auto gload = [&](int k0) {
 #pragma unroll
@@ -107,7 +190,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       if (w_ok[i]) v = *reinterpret_cast<const uint4*>(w_ptr[i] + k0);
       wr[i] = v;
     }
-    // advance tap state
     c0 += BK;
     if (c0 >= p.Cin) {
       c0 = 0;
@@ -133,14 +215,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int KT = p.K / BK;
-  gload(0);
-  lstore(0);
+  if (KT > 0) {
+    gload(kt_begin * BK);
+    lstore(0);
+  }
   __syncthreads();
 
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < KT) gload((kt + 1) * BK);
+    if (kt + 1 < KT) gload((kt_begin + kt + 1) * BK);
     const char* xs = smem + cur * C::TILE_BYTES;
     const char* ws = xs + BM * 128;
 #pragma unroll
@@ -162,82 +245,189 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   }
 
   // ------------------------------- epilogue -------------------------------
-  T* __restrict__ out = reinterpret_cast<T*>(p.out) + z * p.bs_out;
-  const T* __restrict__ res = p.residual ? reinterpret_cast<const T*>(p.residual) + z * p.bs_res : nullptr;
-  const T* __restrict__ rowb = reinterpret_cast<const T*>(p.rowbias);
-
-  if (p.epilogue == AF_EPI_GEGLU) {
+  // phase 1: accumulators -> fp32 LDS tile [BM][BNo (+4)]
+  float* et = reinterpret_cast<float*>(smem);
+  const bool geglu = p.epilogue == AF_EPI_GEGLU;
+  int BNo = BN;  // columns of the staged tile
+  if (geglu) {
     if constexpr (NI == 2) {
-      // rows [g*64, g*64+32) of the packed weight are "value", [g*64+32, g*64+64) "gate"
-      const int g = (n0 + wn * 64) >> 6;
-      const int Nout = p.N >> 1;
+      BNo = BN / 2;
+      // packed weight rows [g*64, g*64+32) are "value", [g*64+32, g*64+64) "gate"; a wave's 64 columns = one group
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * C::WM + mi * 32 + l31;
-        if (m >= p.M) continue;
+        const int row = wm * C::WM + mi * 32 + l31;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int j = 8 * q + 4 * h;           // row inside the 32-row block
-          const int nv = n0 + wn * 64 + j;       // packed row of the value
-          const int no = g * 32 + j;             // output column
-          if (no >= Nout) continue;
-          Quad<T> o;
+          const int j = 8 * q + 4 * h;
+          const int nv = n0 + wn * 64 + j;  // packed row index of the value (bias is packed the same way)
+          float4 o;
+          float* op = reinterpret_cast<float*>(&o);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float val = acc[0][mi][4 * q + e] * p.alpha;
             float gat = acc[1][mi][4 * q + e] * p.alpha;
             if (p.bias) { val += p.bias[nv + e]; gat += p.bias[nv + 32 + e]; }
-            o.e[e] = from_f32<T>(val * gelu_erf_f(gat));
+            op[e] = val * gelu_erf_f(gat);
           }
-          o.store(out + (long)m * p.ldo + no);
+          *reinterpret_cast<float4*>(et + row * C::EPI_LD + wn * 32 + j) = o;
         }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int row = wm * C::WM + mi * 32 + l31;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 o;
+          o.x = acc[ni][mi][4 * q + 0] * p.alpha; o.y = acc[ni][mi][4 * q + 1] * p.alpha;
+          o.z = acc[ni][mi][4 * q + 2] * p.alpha; o.w = acc[ni][mi][4 * q + 3] * p.alpha;
+          *reinterpret_cast<float4*>(et + row * C::EPI_LD + wn * C::WN + ni * 32 + 8 * q + 4 * h) = o;
+        }
+    }
+  }
+  __syncthreads();
+
+  // phase 2: each thread owns 8 consecutive columns of a row; a wave covers whole contiguous rows
+  const int tpr = BNo >> 3;            // threads per row
+  const int rpp = 256 / tpr;           // rows per pass
+  const int trow = tid / tpr, c8 = (tid - trow * tpr) * 8;
+  const int ncol0 = geglu ? (n0 >> 1) : n0;
+  const int Nvalid = geglu ? (p.N >> 1) : p.N;
+  const int n = ncol0 + c8;
+
+  if (p.splitk > 1) {
+    // raw fp32 partial sums into this slice's slab [M][N]
+    float* slab = reinterpret_cast<float*>(p.ws) + (long)zk * p.M * p.N;
+    for (int row = trow; row < BM; row += rpp) {
+      const int m = m0 + row;
+      if (m >= p.M || n >= Nvalid) continue;
+      const float4 a = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8);
+      *reinterpret_cast<float4*>(slab + (long)m * p.N + n) = a;
+      if (n + 4 < Nvalid) {
+        const float4 b4 = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8 + 4);
+        *reinterpret_cast<float4*>(slab + (long)m * p.N + n + 4) = b4;
       }
     }
     return;
   }
 
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int m = m0 + wm * C::WM + mi * 32 + l31;
-    if (m >= p.M) continue;
-    const int b = rowb ? (m / HoWo) : 0;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * C::WN + ni * 32 + 8 * q + 4 * h;
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * q + e] * p.alpha;
-        if (p.bias) {
-          const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-        }
-        if (rowb) {
-          Quad<T> rb;
-          rb.load(rowb + (long)b * p.ldrb + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += to_f32<T>(rb.e[e]);
-        }
-        if (res) {
-          Quad<T> rv;
-          rv.load(res + (long)m * p.ldr + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += to_f32<T>(rv.e[e]);
-        }
-        Quad<T> o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o.e[e] = from_f32<T>(v[e]);
-        o.store(out + (long)m * p.ldo + n);
-      }
+  T* __restrict__ out = reinterpret_cast<T*>(p.out) + zb * p.bs_out;
+  const T* __restrict__ res = p.residual ? reinterpret_cast<const T*>(p.residual) + zb * p.bs_res : nullptr;
+  const T* __restrict__ rowb = reinterpret_cast<const T*>(p.rowbias);
+  const float* __restrict__ bias = geglu ? nullptr : p.bias;
+  if (n < Nvalid) {
+    const int nvalid = min(8, Nvalid - n);
+    for (int row = trow; row < BM; row += rpp) {
+      const int m = m0 + row;
+      if (m >= p.M) break;
+      float v[8];
+      const float4 a = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8);
+      const float4 b4 = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
+      epi_store8<T>(p, v, m, rowb ? m / HoWo : 0, n, nvalid, out, res, rowb, bias);
     }
   }
 }
 
+// split-K reduce + epilogue: out[m][n] = T(sum_z slab[z][m][n] + bias + rowbias + residual)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvGemmParams p) {
+  const long nq = (long)p.M * (p.N >> 2);
+  const float* ws = reinterpret_cast<const float*>(p.ws);
+  const int HoWo = p.Ho * p.Wo;
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+  const T* __restrict__ rowb = reinterpret_cast<const T*>(p.rowbias);
+  T* __restrict__ out = reinterpret_cast<T*>(p.out);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nq; i += (long)gridDim.x * 256) {
+    const int m = (int)(i / (p.N >> 2));
+    const int n = (int)(i - (long)m * (p.N >> 2)) * 4;
+    float4 a = *reinterpret_cast<const float4*>(ws + (long)m * p.N + n);
+    for (int zz = 1; zz < p.splitk; ++zz) {
+      const float4 b4 = *reinterpret_cast<const float4*>(ws + ((long)zz * p.M + m) * p.N + n);
+      a.x += b4.x; a.y += b4.y; a.z += b4.z; a.w += b4.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (p.bias) {
+      const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+      v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    }
+    if (rowb) {
+      Quad<T> rb;
+      rb.load(rowb + (long)(m / HoWo) * p.ldrb + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += to_f32<T>(rb.e[e]);
+    }
+    if (res) {
+      Quad<T> rv;
+      rv.load(res + (long)m * p.ldr + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += to_f32<T>(rv.e[e]);
+    }
+    Quad<T> o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o.e[e] = from_f32<T>(v[e]);
+    o.store(out + (long)m * p.ldo + n);
+  }
+}
+
 // ---------------------------------------------------------------------------
-// host launcher
+// planning (tile shape + split-K) and launch
 // ---------------------------------------------------------------------------
+static int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+// tile: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64
+AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) {
+  AfGemmPlan pl;
+  pl.tile = 0;
+  pl.splitk = 1;
+  pl.ws_bytes = 0;
+  const bool geglu = p.epilogue == AF_EPI_GEGLU;
+  const bool n128 = geglu || (p.N % 128) == 0 || p.N > 640;
+  static const int bm[4] = {128, 64, 128, 64}, bn[4] = {128, 128, 64, 64};
+  static const double eff[4] = {1.0, 0.88, 0.88, 0.72};
+  // cost model: rounds over the 256 CUs x tile area / tile efficiency (per unit of K)
+  double best = 1e30;
+  for (int t = 0; t < 4; ++t) {
+    if (n128 && bn[t] != 128) continue;
+    if (!n128 && bn[t] != 64) continue;
+    const long nb = (long)((p.M + bm[t] - 1) / bm[t]) * ((p.N + bn[t] - 1) / bn[t]) * batch;
+    const double rounds = (double)((nb + 255) / 256);
+    const double cost = rounds * bm[t] * bn[t] / eff[t];
+    if (cost < best) { best = cost; pl.tile = t; }
+  }
+  const int BK = 128 / elem_size;
+  const int KT = p.K / BK;
+  const long nb = (long)((p.M + bm[pl.tile] - 1) / bm[pl.tile]) * ((p.N + bn[pl.tile] - 1) / bn[pl.tile]) * batch;
+  if (batch == 1 && !geglu && nb < 256 && KT >= 16) {
+    // deep-K, few tiles: slice K so that ~2 blocks per CU exist, each slice >= 8 K tiles
+    const int target = env_int("AF_SPLITK_TARGET", 320);
+    int s = (int)((target + nb - 1) / nb);
+    if (s > KT / 8) s = KT / 8;
+    if (s > 16) s = 16;
+    if (s >= 2) {
+      // prefer the big tile when slicing K
+      pl.tile = n128 ? 0 : 2;
+      const long nb2 = (long)((p.M + bm[pl.tile] - 1) / bm[pl.tile]) * ((p.N + bn[pl.tile] - 1) / bn[pl.tile]);
+      s = (int)((target + nb2 - 1) / nb2);
+      if (s > KT / 8) s = KT / 8;
+      if (s > 16) s = 16;
+      if (s >= 2) pl.splitk = s;
+    }
+  }
+  const int ft = env_int("AF_GEMM_TILE", -1);
+  if (ft >= 0 && ft < 4 && !(geglu && bn[ft] != 128)) pl.tile = ft;
+  const int fs = env_int("AF_GEMM_SPLITK", -1);
+  if (fs >= 1 && batch == 1 && !geglu) pl.splitk = fs > KT ? KT : fs;
+  if (pl.splitk > 1) pl.ws_bytes = (size_t)pl.splitk * p.M * p.N * sizeof(float);
+  return pl;
+}
+
 template <typename T, int BM, int BN>
 static int launch_cfg(const ConvGemmParams& p, int batch, hipStream_t stream) {
   using C = TileCfg<BM, BN>;
@@ -247,14 +437,17 @@ static int launch_cfg(const ConvGemmParams& p, int batch, hipStream_t stream) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_set = true;
   }
-  dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, batch);
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  dim3 grid(ntm * ntn, 1, p.splitk > 1 ? p.splitk : batch);
   hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN>), grid, dim3(256), C::LDS_BYTES, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 
-template <typename T> int af_launch_conv_gemm(const ConvGemmParams& p, int batch, hipStream_t stream) {
+template <typename T>
+int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t stream, const AfGemmPlan* plan, void* ws) {
   constexpr int BK = 128 / sizeof(T);
+  ConvGemmParams p = p_in;
   if (p.K % BK != 0 || p.Cin % BK != 0 || p.K != p.ks * p.ks * p.Cin) {
     af_set_error_msg("conv_gemm: K=%d Cin=%d ks=%d must satisfy K==ks*ks*Cin and Cin%%%d==0", p.K, p.Cin, p.ks, BK);
     return -1;
@@ -267,22 +460,31 @@ template <typename T> int af_launch_conv_gemm(const ConvGemmParams& p, int batch
     af_set_error_msg("conv_gemm: N/ldo/ldr/ldrb must be multiples of 4 (N=%d ldo=%d)", p.N, p.ldo);
     return -1;
   }
+  if (p.epilogue == AF_EPI_GEGLU && p.N % 64 != 0) { af_set_error_msg("conv_gemm: GEGLU needs N%%64==0"); return -1; }
   if (p.M <= 0 || p.N <= 0) return 0;
+  AfGemmPlan pl = plan ? *plan : af_plan_conv_gemm(p, batch, (int)sizeof(T));
+  if (pl.splitk > 1 && !ws) pl.splitk = 1;  // no workspace supplied: fall back to one slice
+  p.splitk = pl.splitk;
+  p.ws = ws;
   AfProfScope prof(AF_K_CONV_GEMM, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K) * batch,
                    ((double)p.M * p.K / (p.ks * p.ks) + (double)p.N * p.K + (double)p.M * p.N) * batch * sizeof(T));
-  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-  if (p.epilogue == AF_EPI_GEGLU) {
-    if (p.N % 64 != 0) { af_set_error_msg("conv_gemm: GEGLU needs N%%64==0"); return -1; }
-    return t128 >= 256 ? launch_cfg<T, 128, 128>(p, batch, stream) : launch_cfg<T, 64, 128>(p, batch, stream);
+  int rc;
+  switch (pl.tile) {
+    case 0: rc = launch_cfg<T, 128, 128>(p, batch, stream); break;
+    case 1: rc = launch_cfg<T, 64, 128>(p, batch, stream); break;
+    case 2: rc = launch_cfg<T, 128, 64>(p, batch, stream); break;
+    default: rc = launch_cfg<T, 64, 64>(p, batch, stream); break;
   }
-  const bool n128 = (p.N % 128) == 0;
-  if (n128) {
-    return t128 >= 256 ? launch_cfg<T, 128, 128>(p, batch, stream) : launch_cfg<T, 64, 128>(p, batch, stream);
-  } else {
-    const long t = (long)((p.M + 127) / 128) * ((p.N + 63) / 64) * batch;
-    return t >= 256 ? launch_cfg<T, 128, 64>(p, batch, stream) : launch_cfg<T, 64, 64>(p, batch, stream);
+  if (rc) return rc;
+  if (p.splitk > 1) {
+    const long nq = (long)p.M * (p.N >> 2);
+    unsigned blocks = (unsigned)((nq + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, stream, p);
+    HIP_CHECK_RET(hipGetLastError());
   }
+  return 0;
 }
 
-template int af_launch_conv_gemm<bf16>(const ConvGemmParams&, int, hipStream_t);
-template int af_launch_conv_gemm<float>(const ConvGemmParams&, int, hipStream_t);
+template int af_launch_conv_gemm<bf16>(const ConvGemmParams&, int, hipStream_t, const AfGemmPlan*, void*);
+template int af_launch_conv_gemm<float>(const ConvGemmParams&, int, hipStream_t, const AfGemmPlan*, void*);

@@ -2,7 +2,10 @@
 #pragma once
 #include "af_common.h"
 
-template <typename T> int af_launch_conv_gemm(const ConvGemmParams& p, int batch, hipStream_t stream);
+AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size);
+template <typename T>
+int af_launch_conv_gemm(const ConvGemmParams& p, int batch, hipStream_t stream, const AfGemmPlan* plan = nullptr,
+                        void* ws = nullptr);
 template <typename T> int af_launch_attention(const AttnParams& p, int B, int dh, hipStream_t stream);
 
 size_t af_gn_workspace_bytes(int B, int HW);

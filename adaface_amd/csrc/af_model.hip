@@ -578,7 +578,6 @@ struct Runner {
   int conv(const Linear& L, const Act& x, Act& out, int stride, int up, const Act* residual, const void* rowbias,
            int ldrb, int n_valid = -1) {
     AF_TRY(check(out));
-    if (dry) return 0;
     ConvGemmParams p;
     memset(&p, 0, sizeof(p));
     p.src = x.p;
@@ -606,7 +605,16 @@ struct Runner {
       af_set_error_msg("conv: input has %d channels (ld %d), layer expects %d (padded %d)", x.C, x.ld, L.cin, L.cin_pad);
       return AF_ERR_INVALID;
     }
-    return DISPATCH(dt, af_launch_conv_gemm<bf16>(p, 1, s), af_launch_conv_gemm<float>(p, 1, s));
+    const AfGemmPlan pl = af_plan_conv_gemm(p, 1, (int)esize(dt));
+    void* ws = nullptr;
+    if (pl.splitk > 1) {
+      const size_t mk = A.mark();
+      ws = A.alloc(pl.ws_bytes);  // consumed by the reduce kernel enqueued in this call; later allocations
+      A.release(mk);              // are only touched by later (stream-ordered) kernels
+      if (!ws) { af_set_error_msg("arena exhausted (split-K slabs)"); return AF_ERR_STATE; }
+    }
+    if (dry) return 0;
+    return DISPATCH(dt, af_launch_conv_gemm<bf16>(p, 1, s, &pl, ws), af_launch_conv_gemm<float>(p, 1, s, &pl, ws));
   }
   int gemm_raw(const ConvGemmParams& p, int batch) {
     if (dry) return 0;

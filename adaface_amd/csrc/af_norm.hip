@@ -229,9 +229,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 // ---------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------
-int af_gn_chunking(int HW, int* P_out) {
-  int P = 64;
-  while ((HW + P - 1) / P > 256) P *= 2;
+// pixels per block: aim for ~1024 blocks over (chunks x samples) so that 8x8 / 16x16 feature maps still fill the
+// chip, at least 4 pixels per block, at most 1024 chunks per sample (the finalize kernel loops over them)
+int af_gn_chunking(int HW, int B, int* P_out) {
+  int P = 4;
+  while (P < 64 && (long)((HW + P - 1) / P) * B > 1024) P *= 2;
+  while ((HW + P - 1) / P > 1024) P *= 2;
   *P_out = P;
   return (HW + P - 1) / P;
 }
@@ -239,7 +242,7 @@ int af_gn_chunking(int HW, int* P_out) {
 // workspace: partial [B][nchunk][32][2] floats + stats [B][32][2] floats
 size_t af_gn_workspace_bytes(int B, int HW) {
   int P;
-  int nchunk = af_gn_chunking(HW, &P);
+  int nchunk = af_gn_chunking(HW, B, &P);
   return ((size_t)B * nchunk * GN_GROUPS * 2 + (size_t)B * GN_GROUPS * 2) * sizeof(float);
 }
 
@@ -253,7 +256,7 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
     return -1;
   }
   int P;
-  const int nchunk = af_gn_chunking(HW, &P);
+  const int nchunk = af_gn_chunking(HW, B, &P);
   AfProfScope prof(AF_K_GROUPNORM, stream, 0.0, 2.0 * B * HW * (double)Cn * sizeof(T));
   float* partial = reinterpret_cast<float*>(workspace);
   float* stats = partial + (size_t)B * nchunk * GN_GROUPS * 2;

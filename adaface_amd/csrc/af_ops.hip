@@ -79,7 +79,11 @@ int af_op_conv2d(int dtype, const float* x_dev, const float* w_dev, const float*
   p.W = wn; p.ldw = ldw; p.Wrows = rows_pad;
   p.M = B * Ho * Wo; p.N = co4; p.K = ldw;
   p.bias = bn; p.residual = rn; p.ldr = co4; p.out = yn; p.ldo = co4; p.alpha = 1.f;
-  OP_TRY(DISP(dtype, af_launch_conv_gemm<bf16>(p, 1, s), af_launch_conv_gemm<float>(p, 1, s)));
+  p.k_logical = ks * ks * Cin;
+  const AfGemmPlan pl = af_plan_conv_gemm(p, 1, (int)esz(dtype));
+  void* ws = nullptr;
+  if (pl.splitk > 1) { ws = tmp.get(pl.ws_bytes, false); if (!ws) return AF_ERR_HIP; }
+  OP_TRY(DISP(dtype, af_launch_conv_gemm<bf16>(p, 1, s, &pl, ws), af_launch_conv_gemm<float>(p, 1, s, &pl, ws)));
   OP_TRY(DISP(dtype, af_launch_nhwc_to_nchw<bf16>(yn, y_dev, B, Cout, Ho * Wo, co4, s),
               af_launch_nhwc_to_nchw<float>(yn, y_dev, B, Cout, Ho * Wo, co4, s)));
   return 0;
@@ -124,7 +128,11 @@ int af_op_linear(int dtype, const float* x_dev, const float* w_dev, const float*
   p.bias = bn; p.residual = rn; p.ldr = no4; p.out = yn; p.ldo = no4;
   p.epilogue = geglu ? AF_EPI_GEGLU : AF_EPI_NONE;
   p.alpha = 1.f;
-  OP_TRY(DISP(dtype, af_launch_conv_gemm<bf16>(p, 1, s), af_launch_conv_gemm<float>(p, 1, s)));
+  p.k_logical = K;
+  const AfGemmPlan pl = af_plan_conv_gemm(p, 1, (int)esz(dtype));
+  void* ws = nullptr;
+  if (pl.splitk > 1) { ws = tmp.get(pl.ws_bytes, false); if (!ws) return AF_ERR_HIP; }
+  OP_TRY(DISP(dtype, af_launch_conv_gemm<bf16>(p, 1, s, &pl, ws), af_launch_conv_gemm<float>(p, 1, s, &pl, ws)));
   OP_TRY(DISP(dtype, af_launch_nhwc_to_nchw<bf16>(yn, y_dev, (int)M, N, 1, no4, s),
               af_launch_nhwc_to_nchw<float>(yn, y_dev, (int)M, N, 1, no4, s)));
   return 0;
