@@ -21,7 +21,10 @@ BUILD = PKG / "_build"
 LIB = PKG / "libadaface_hip.so"
 SOURCES = ["af_conv_gemm.hip", "af_norm.hip", "af_attention.hip", "af_elementwise.hip", "af_model.hip", "af_ops.hip"]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-Wno-unused-value"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-Wno-unused-value",
+         # MFMA accumulators in VGPRs (gfx950 has one unified register file): no v_accvgpr_read/write around the
+         # softmax / epilogue VALU work, and fewer registers in total
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc() -> str:

@@ -7,12 +7,19 @@
 //
 // Structure (wave64, MFMA 32x32):
 //   * grid (ceil(Nq/128), heads, batch); 4 waves, each owns 32 query rows.
-//   * K/V are staged per 64-key tile in LDS: K row-major (row stride padded by
-//     16 B -> conflict-free ds_read_b128), V TRANSPOSED ([d][key]) so the PV
-//     product reads its A operand with 8/16-byte LDS reads.
+//   * K/V staged per 64-key tile in LDS.  bf16: both row-major, double-buffered, the
+//     next tile's global loads are issued into registers before the current tile's
+//     MFMAs and written to the other buffer after them (one barrier per tile).
+//     K rows are padded by 16 B (conflict-free ds_read_b128); V rows use a stride
+//     = 64 or 192 (mod 256) so the hardware-transposing ds_read_b64_tr_b16 that
+//     feeds V^T as the MFMA A operand is conflict-free.  f32 (parity mode): single
+//     buffer, V staged transposed (no 32-bit transposing read exists).
 //   * swapped QK^T: S^T = K . Q^T, so a lane holds ONE query column and 16 keys
 //     per 32x32 block in registers; the online-softmax max/sum are register
-//     reductions plus one cross-half shuffle.
+//     reductions plus one v_permlane32_swap across the two lane halves.
+//   * Q is pre-multiplied by scale*log2(e) once, so softmax is exp2(s - m) with a
+//     bare v_exp_f32; keys are masked only in the last (partial) tile; the O
+//     accumulator is rescaled only when some lane's running max actually moved.
 //   * the S^T accumulator is fed straight back as the B operand of O^T = V^T . P^T
 //     (accumulator-as-operand: register r of lane-half h is key (r&3)+8(r>>2)+4h,
 //     the V^T fragment is read in that same key order), no LDS round trip for P.
@@ -21,24 +28,50 @@
 #include "af_common.h"
 #include <math.h>
 
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
 template <typename T, int DH> struct AttnCfg {
+  static constexpr bool BF = sizeof(T) == 2;
   static constexpr int EPC = 16 / sizeof(T);
   static constexpr int FS = (DH * (int)sizeof(T) + 31) / 32;   // 32-byte steps along d
   static constexpr int KROW = FS * 32 + 16;                    // bytes
   static constexpr int DB = (DH + 31) / 32;                    // 32-wide d blocks
-  static constexpr int VROW = 64 * (int)sizeof(T) + (sizeof(T) == 2 ? 8 : 16);
+  // bf16: V row-major [64 keys][VROW], VROW >= DB*64 and == 64 or 192 (mod 256)
+  static constexpr int VROW_BF = (DB * 64 <= 64) ? 64 : (DB * 64 <= 192) ? 192 : 320;
+  // f32: V transposed [DB*32][64 keys * 4 + 16]
+  static constexpr int VROW_F32 = 64 * 4 + 16;
   static constexpr int K_BYTES = 64 * KROW;
-  static constexpr int V_BYTES = DB * 32 * VROW;
-  static constexpr int LDS_BYTES = K_BYTES + V_BYTES;
+  static constexpr int V_BYTES = BF ? 64 * VROW_BF : DB * 32 * VROW_F32;
+  static constexpr int TILE = K_BYTES + V_BYTES;
+  static constexpr int NBUF = BF ? 2 : 1;
+  static constexpr int LDS_BYTES = NBUF * TILE;
+  static constexpr int CPR = DH / EPC;                         // valid 16-byte chunks per key row
+  static constexpr int NLD = (64 * CPR + 255) / 256;           // staged chunks per thread (K and V each)
+  // a free padding column d = DH of the V tile holds 1.0 for valid keys: row DH of O^T is then the softmax
+  // denominator, summed by the MFMA instead of 32 VALU adds per tile (bf16 only; needs DH % 32 != 0)
+  static constexpr bool ONES = BF && (DH % 32) != 0;
 };
+
+__device__ __forceinline__ float xhalf_max(float v) {
+  const unsigned b = __builtin_bit_cast(unsigned, v);
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
+// one v_max3_f32 (plain fmaxf on MFMA outputs makes hipcc insert a canonicalising v_max per operand)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 
 template <typename T, int DH>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   using C = AttnCfg<T, DH>;
-  constexpr int EPC = C::EPC, FS = C::FS, KROW = C::KROW, DB = C::DB, VROW = C::VROW;
+  constexpr bool BF = C::BF;
+  constexpr int EPC = C::EPC, FS = C::FS, KROW = C::KROW, DB = C::DB, CPR = C::CPR, NLD = C::NLD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ks = smem;
-  char* vt = smem + C::K_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -52,14 +85,21 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   const T* V = reinterpret_cast<const T*>(p.v) + (long)b * p.bsv + head * DH;
   T* O = reinterpret_cast<T*>(p.o) + (long)b * p.bso + head * DH;
 
-  // Q fragments (B operand of S^T = K Q^T): lane (q, h) holds d = (32s+16h)/sizeof(T) ...
+  // zero the whole LDS once: padding chunks (d >= DH) are never written again and must not hold NaNs
+  for (int i = tid; i < C::LDS_BYTES / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+
+  // Q fragments (B operand of S^T = K Q^T), pre-multiplied by scale*log2(e)
+  const float sl2 = p.scale * 1.44269504088896340736f;
   uint4 qf[FS];
 #pragma unroll
   for (int s = 0; s < FS; ++s) {
     const int d0 = (32 * s + 16 * h) / (int)sizeof(T);
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (q_ok && d0 < DH) v = *reinterpret_cast<const uint4*>(Q + (long)q * p.ldq + d0);
-    qf[s] = v;
+    Vec16<T> v;
+    v.u = make_uint4(0, 0, 0, 0);
+    if (q_ok && d0 < DH) v.u = *reinterpret_cast<const uint4*>(Q + (long)q * p.ldq + d0);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) v.e[e] = from_f32<T>(to_f32<T>(v.e[e]) * sl2);
+    qf[s] = v.u;
   }
 
   f32x16 o[DB];
@@ -68,38 +108,65 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  const float sl2 = p.scale * 1.44269504088896340736f;
 
-  for (int t0 = 0; t0 < p.Nk; t0 += 64) {
-    __syncthreads();
-    // ---- stage K tile: [64][KROW], chunks beyond DH and keys beyond Nk are zero ----
-    {
-      constexpr int CPR = FS * 2;  // 16-byte chunks per LDS row
-      for (int idx = tid; idx < 64 * CPR; idx += 256) {
-        const int row = idx / CPR, ch = idx - row * CPR;
-        const int key = t0 + row;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (key < p.Nk && ch * EPC < DH) v = *reinterpret_cast<const uint4*>(K + (long)key * p.ldk + ch * EPC);
-        *reinterpret_cast<uint4*>(ks + row * KROW + ch * 16) = v;
-      }
-    }
-    // ---- stage V tile transposed: vt[d][key]; rows d >= DH zero, keys >= Nk zero ----
-    {
-      constexpr int NCH = DB * 32 / EPC;  // chunks per key incl. padding rows
-      const int krow = tid & 63;
-      const int key = t0 + krow;
-      for (int ch = tid >> 6; ch < NCH; ch += 4) {
-        Vec16<T> v;
-        v.u = make_uint4(0, 0, 0, 0);
-        if (key < p.Nk && ch * EPC < DH) v.u = *reinterpret_cast<const uint4*>(V + (long)key * p.ldv + ch * EPC);
+  // ---- staging helpers ----
+  uint4 kreg[NLD], vreg[NLD];
+  unsigned short ones_val[NLD];
+  auto gload = [&](int t0) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e)
-          *reinterpret_cast<T*>(vt + (ch * EPC + e) * VROW + krow * (int)sizeof(T)) = v.e[e];
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / CPR, ch = idx - row * CPR;
+      const int key = t0 + row;
+      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+      if (idx < 64 * CPR && key < p.Nk) {
+        kv = *reinterpret_cast<const uint4*>(K + (long)key * p.ldk + ch * EPC);
+        vv = *reinterpret_cast<const uint4*>(V + (long)key * p.ldv + ch * EPC);
+      }
+      kreg[i] = kv;
+      vreg[i] = vv;
+      ones_val[i] = (idx < 64 * CPR && key < p.Nk) ? (unsigned short)0x3F80 : (unsigned short)0;
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* ks = smem + buf * C::TILE;
+    char* vs = ks + C::K_BYTES;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < 64 * CPR) {
+        const int row = idx / CPR, ch = idx - row * CPR;
+        *reinterpret_cast<uint4*>(ks + row * KROW + ch * 16) = kreg[i];
+        if constexpr (BF) {
+          *reinterpret_cast<uint4*>(vs + row * C::VROW_BF + ch * 16) = vreg[i];
+          if constexpr (C::ONES)
+            if (ch == 0)
+              *reinterpret_cast<unsigned short*>(vs + row * C::VROW_BF + DH * 2) = ones_val[i];
+        } else {
+          Vec16<T> v;
+          v.u = vreg[i];
+#pragma unroll
+          for (int e = 0; e < EPC; ++e)
+            *reinterpret_cast<T*>(vs + (ch * EPC + e) * C::VROW_F32 + row * (int)sizeof(T)) = v.e[e];
+        }
       }
     }
-    __syncthreads();
+  };
 
-    // ---- S^T = K Q^T : two 32-key blocks ----
+  const int nt = (p.Nk + 63) / 64;
+  __syncthreads();  // zero fill done
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int t0 = t * 64;
+    const int buf = (C::NBUF == 2) ? (t & 1) : 0;
+    if (t + 1 < nt) gload(t0 + 64);
+    const char* ks = smem + buf * C::TILE;
+    const char* vs = ks + C::K_BYTES;
+
+    // ---- S^T = K Q^T : two 32-key blocks (scores already in the log2 domain) ----
     f32x16 s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -111,39 +178,47 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         Mma<T>::step(a, qf[st], s[kb]);
       }
     }
-    // ---- online softmax (per lane = per query; halves hold disjoint keys) ----
-    float mx = -INFINITY;
+    if (t0 + 64 > p.Nk) {  // partial last tile: mask keys >= Nk (wave-uniform branch)
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = t0 + 32 * kb + acc_row(r, h);
-        float v = s[kb][r] * sl2;
-        if (key >= p.Nk) v = -INFINITY;
-        s[kb][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        for (int r = 0; r < 16; ++r)
+          if (t0 + 32 * kb + acc_row(r, h) >= p.Nk) s[kb][r] = -INFINITY;
+    }
+    // ---- online softmax (per lane = per query; the two lane halves hold disjoint keys) ----
+    float mx = max3f(s[0][0], s[1][0], s[0][1]);
+    mx = max3f(mx, s[1][1], s[0][2]);
+#pragma unroll
+    for (int r = 2; r < 15; r += 2) {
+      mx = max3f(mx, s[1][r], s[0][r + 1]);
+      mx = max3f(mx, s[1][r + 1], (r + 2 < 16) ? s[0][r + 2] : s[1][r + 1]);
+    }
+    mx = xhalf_max(mx);
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(s[kb][r] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
         s[kb][r] = pv;
-        psum += pv;
+        if constexpr (!C::ONES) psum += pv;
       }
-    l_run = l_run * alpha + psum;
+    if constexpr (!C::ONES) l_run = l_run * alpha + psum;
     m_run = m_new;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {  // rescale only when some lane's max moved
 #pragma unroll
-    for (int d = 0; d < DB; ++d)
+      for (int d = 0; d < DB; ++d)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
 
     // ---- O^T += V^T P^T ----
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (BF) {
+      // lane -> address of its 4-element row piece for ds_read_b64_tr_b16 (16-lane groups, 4 rows x 16 cols)
+      const int tq = (lane & 15) >> 2, tp = lane & 3, gi = (lane >> 4) & 1;
+      const char* vlane = vs + (4 * h + tq) * C::VROW_BF + (16 * gi + 4 * tp) * 2;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -151,13 +226,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
           Vec16<T> pb;
 #pragma unroll
           for (int j = 0; j < 8; ++j) pb.e[j] = from_f32<T>(s[kb][8 * s2 + j]);
-          const int key0 = 32 * kb + 16 * s2 + 4 * h;
+          const char* vrow = vlane + (32 * kb + 16 * s2) * C::VROW_BF;
 #pragma unroll
           for (int d = 0; d < DB; ++d) {
-            const char* row = vt + (32 * d + l31) * VROW;
-            const uint2 lo = *reinterpret_cast<const uint2*>(row + key0 * 2);
-            const uint2 hi = *reinterpret_cast<const uint2*>(row + (key0 + 8) * 2);
-            const uint4 a = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(vrow + 64 * d));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(vrow + 8 * C::VROW_BF + 64 * d));
+            const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
+            const uint4 a = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
             Mma<T>::step(a, pb.u, o[d]);
           }
         }
@@ -172,14 +248,25 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
           const int key0 = 32 * kb + 8 * g + 4 * h;
 #pragma unroll
           for (int d = 0; d < DB; ++d) {
-            const uint4 a = *reinterpret_cast<const uint4*>(vt + (32 * d + l31) * VROW + key0 * 4);
+            const uint4 a = *reinterpret_cast<const uint4*>(vs + (32 * d + l31) * C::VROW_F32 + key0 * 4);
             Mma<T>::step(a, pb.u, o[d]);
           }
         }
     }
+
+    if (C::NBUF == 1) __syncthreads();  // single buffer: everyone has finished reading before it is rewritten
+    if (t + 1 < nt) lstore((C::NBUF == 2) ? ((t + 1) & 1) : 0);
+    __syncthreads();
   }
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_tot;
+  if constexpr (C::ONES) {
+    // row DH of O^T: block DH/32, in-block row rr -> register (rr&3)+4*(rr>>3) of lane-half (rr>>2)&1
+    constexpr int rr = DH % 32, ob = DH / 32, oreg = (rr & 3) + 4 * (rr >> 3), oh = (rr >> 2) & 1;
+    l_tot = __shfl(o[ob][oreg], l31 + 32 * oh, 64);
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  }
   const float inv = 1.0f / l_tot;
   if (q_ok) {
 #pragma unroll
