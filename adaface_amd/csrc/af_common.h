@@ -84,8 +84,23 @@ template <> struct Quad<float> {
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 // exact (erf) GELU, as F.gelu default (attention.py:41)
+// erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 rounding level): one v_rcp, one v_exp and a
+// degree-5 Horner chain instead of libm's branchy erff — the GEGLU epilogue evaluates it 8192 times per tile and
+// was the dominant cost of the K=320 feed-forward projections.
+__device__ __forceinline__ float erf_as_f(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * ax * ax);
+  const float r = fmaf(-poly, e, 1.0f);
+  return copysignf(r, x);
+}
 __device__ __forceinline__ float gelu_erf_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f));
 }
 
 // ---------------------------------------------------------------------------
@@ -162,6 +177,7 @@ struct AfGemmPlan {
   int tile;         // 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64
   int splitk;       // >= 1
   size_t ws_bytes;  // fp32 slab workspace needed when splitk > 1
+  int halo_tw;      // 0 = implicit-GEMM kernel; 16 / 32 = LDS-halo 3x3 kernel with that patch width
 };
 
 struct AttnParams {

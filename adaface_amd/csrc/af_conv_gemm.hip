@@ -123,15 +123,22 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   const long zb = p.splitk > 1 ? 0 : z;   // batch index
   const int zk = p.splitk > 1 ? (int)z : 0;  // K slice
 
-  const T* __restrict__ src = reinterpret_cast<const T*>(p.src) + zb * p.bs_src;
-  const T* __restrict__ Wt = reinterpret_cast<const T*>(p.W) + zb * p.bs_w;
+  // Buffer resources (wave-uniform base, 32-bit per-lane byte offsets).  Lanes that must read zero (image
+  // padding, rows beyond M / Wrows) get voffset 0xFFFFFFFF: the hardware range check returns 0 for them, so the
+  // gather needs neither branches nor 64-bit address arithmetic.
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(reinterpret_cast<const T*>(p.src) + zb * p.bs_src), 0, (int)0xFFFFFFF0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(reinterpret_cast<const T*>(p.W) + zb * p.bs_w), 0, (int)0xFFFFFFF0u, 0x00020000);
 
   const int chunk = tid & 7, r0 = tid >> 3;
   const int HoWo = p.Ho * p.Wo;
+  const unsigned ldcb = (unsigned)p.ldc * (unsigned)sizeof(T);
 
   // --- per-thread gather state for the activation rows it stages ---
   int x_iy0[XR], x_ix0[XR];
-  long x_base[XR];
+  unsigned x_off[XR];
   bool x_ok[XR];
 #pragma unroll
   for (int i = 0; i < XR; ++i) {
@@ -144,16 +151,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     int ox = rem - oy * p.Wo;
     x_iy0[i] = oy * p.stride - p.pad;
     x_ix0[i] = ox * p.stride - p.pad;
-    x_base[i] = (long)b * p.src_batch_stride;
+    x_off[i] = (unsigned)((long)b * p.src_batch_stride * (long)sizeof(T)) + (unsigned)(chunk * 16);
     x_ok[i] = ok;
   }
-  const T* w_ptr[WR];
-  bool w_ok[WR];
+  unsigned w_off[WR];
 #pragma unroll
   for (int i = 0; i < WR; ++i) {
     int n = n0 + r0 + 32 * i;
-    w_ok[i] = n < p.Wrows;
-    w_ptr[i] = Wt + (long)(w_ok[i] ? n : 0) * p.ldw + chunk * EPC;
+    w_off[i] = n < p.Wrows ? (unsigned)(((long)n * p.ldw) * (long)sizeof(T)) + (unsigned)(chunk * 16) : 0xFFFFFFFFu;
   }
 
   // K range of this block
@@ -163,7 +168,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   const int kt_end = min(KT_all, kt_begin + kt_per);
   const int KT = kt_end - kt_begin;
 
-  uint4 xr[XR], wr[WR];
   int ky, kx, c0;  // filter tap and channel offset of the NEXT tile to load
   {
     const int k0 = kt_begin * BK;
@@ -173,30 +177,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     kx = tap - ky * p.ks;
   }
 
-  auto gload = [&](int k0) {
+  auto gload = [&](uint4 (&xr)[XR], uint4 (&wr)[WR], int k0) {
+    const unsigned c0b = (unsigned)c0 * (unsigned)sizeof(T);
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
-      int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
-      bool ok = x_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      int sy = ok ? (iy >> p.up) : 0, sx = ok ? (ix >> p.up) : 0;
-      const T* ptr = src + x_base[i] + ((long)(sy * p.Ws + sx)) * p.ldc + c0 + chunk * EPC;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *reinterpret_cast<const uint4*>(ptr);
-      xr[i] = v;
+      const int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
+      const bool ok = x_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      const unsigned pix = (unsigned)((iy >> p.up) * p.Ws + (ix >> p.up));
+      const unsigned vo = ok ? x_off[i] + pix * ldcb : 0xFFFFFFFFu;
+      xr[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, c0b, 0));
     }
+    const unsigned k0b = (unsigned)k0 * (unsigned)sizeof(T);
 #pragma unroll
-    for (int i = 0; i < WR; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (w_ok[i]) v = *reinterpret_cast<const uint4*>(w_ptr[i] + k0);
-      wr[i] = v;
-    }
+    for (int i = 0; i < WR; ++i)
+      wr[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[i], k0b, 0));
     c0 += BK;
     if (c0 >= p.Cin) {
       c0 = 0;
       if (++kx >= p.ks) { kx = 0; ++ky; }
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const uint4 (&xr)[XR], const uint4 (&wr)[WR]) {
     char* xs = smem + buf * C::TILE_BYTES;
     char* ws = xs + BM * 128;
 #pragma unroll
@@ -215,32 +216,52 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  if (KT > 0) {
-    gload(kt_begin * BK);
-    lstore(0);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < KT) gload((kt_begin + kt + 1) * BK);
-    const char* xs = smem + cur * C::TILE_BYTES;
+  // one K tile from LDS buffer `buf`; the fragments of k-step s+1 are read while step s multiplies
+  auto compute = [&](int buf) {
+    const char* xs = smem + buf * C::TILE_BYTES;
     const char* ws = xs + BM * 128;
+    uint4 xf[2][MI], wf[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      xf[0][mi] = *reinterpret_cast<const uint4*>(xs + lds_off(wm * C::WM + mi * 32 + l31, h));
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      wf[0][ni] = *reinterpret_cast<const uint4*>(ws + lds_off(wn * C::WN + ni * 32 + l31, h));
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      uint4 xf[MI], wf[NI];
+      if (s < 3) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        xf[mi] = *reinterpret_cast<const uint4*>(xs + lds_off(wm * C::WM + mi * 32 + l31, 2 * s + h));
+        for (int mi = 0; mi < MI; ++mi)
+          xf[(s + 1) & 1][mi] =
+              *reinterpret_cast<const uint4*>(xs + lds_off(wm * C::WM + mi * 32 + l31, 2 * (s + 1) + h));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          wf[(s + 1) & 1][ni] =
+              *reinterpret_cast<const uint4*>(ws + lds_off(wn * C::WN + ni * 32 + l31, 2 * (s + 1) + h));
+      }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        wf[ni] = *reinterpret_cast<const uint4*>(ws + lds_off(wn * C::WN + ni * 32 + l31, 2 * s + h));
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) Mma<T>::step(wf[ni], xf[mi], acc[ni][mi]);
+        for (int mi = 0; mi < MI; ++mi) Mma<T>::step(wf[s & 1][ni], xf[s & 1][mi], acc[ni][mi]);
     }
-    if (kt + 1 < KT) lstore(cur ^ 1);
+  };
+
+  // Two register sets: while tile kt is multiplied from LDS, tile kt+1 sits in one set (loaded a whole
+  // iteration ago, so its ds_write does not wait) and tile kt+2's loads are issued into the other.
+  uint4 xa[XR], wa[WR], xb[XR], wb[WR];
+  if (KT > 0) gload(xa, wa, kt_begin * BK);
+  if (KT > 1) gload(xb, wb, (kt_begin + 1) * BK);
+  if (KT > 0) lstore(0, xa, wa);
+  __syncthreads();
+  for (int kt = 0; kt < KT; kt += 2) {
+    if (kt + 2 < KT) gload(xa, wa, (kt_begin + kt + 2) * BK);
+    compute(0);
+    if (kt + 1 < KT) lstore(1, xb, wb);
+    __syncthreads();
+    if (kt + 1 >= KT) break;
+    if (kt + 3 < KT) gload(xb, wb, (kt_begin + kt + 3) * BK);
+    compute(1);
+    if (kt + 2 < KT) lstore(0, xa, wa);
     __syncthreads();
   }
 
@@ -328,6 +349,233 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       const float4 b4 = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8 + 4);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
       epi_store8<T>(p, v, m, rowb ? m / HoWo : 0, n, nvalid, out, res, rowb, bias);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with an LDS-resident input halo.
+//
+// The implicit-GEMM kernel above re-gathers every input pixel 9 times (once per filter tap); at the 64x64 and
+// 32x32 levels that gather, not the MFMA, sets the speed (L2 -> LDS traffic per FLOP).  Here one workgroup owns a
+// TH x TW patch of output pixels of one image (128 pixels): for each 128-byte channel chunk the (TH+2)x(TW+2) input
+// halo is staged ONCE and the nine taps read their MFMA operand from it at shifted row addresses; only the weight
+// tile streams per tap.  Activation traffic drops ~7x (halo overhead 1.4-1.6x instead of 9x).
+// K is walked as (channel chunk, tap) instead of (tap, channel chunk) — the same sum.
+// ---------------------------------------------------------------------------
+template <int TW, int BN> struct HaloCfg {
+  static constexpr int TH = 128 / TW;
+  static constexpr int HWD = TW + 2, HHT = TH + 2, HROWS = HHT * HWD;
+  static constexpr int HALO_BYTES = HROWS * 128;
+  static constexpr int W_BYTES = BN * 128;
+  static constexpr int NHL = (HROWS * 8 + 255) / 256;  // halo 16-byte chunks per thread
+  static constexpr int WR = BN / 32;
+  static constexpr int WN = BN / 2, NI = WN / 32, MI = 2;
+  static constexpr int EPI_LD = BN + 4;
+  static constexpr int EPI_BYTES = 128 * EPI_LD * 4;
+  static constexpr int MAIN_BYTES = HALO_BYTES + 2 * W_BYTES;
+  static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+};
+
+template <typename T, int TW, int BN>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams p) {
+  using C = HaloCfg<TW, BN>;
+  constexpr int BK = 128 / sizeof(T);
+  constexpr int MI = C::MI, NI = C::NI, WR = C::WR, NHL = C::NHL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* wt = smem + C::HALO_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  const int H = p.Ho, W = p.Wo;
+  const int tiles_x = W / TW, tpi = tiles_x * (H / C::TH);
+  const int ntn = (p.N + BN - 1) / BN;
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int tm = wg / ntn, tn = wg - tm * ntn;
+  const int b = tm / tpi, tt = tm - b * tpi;
+  const int ty0 = (tt / tiles_x) * C::TH, tx0 = (tt - (tt / tiles_x) * tiles_x) * TW;
+  const int n0 = tn * BN;
+
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)0xFFFFFFF0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)0xFFFFFFF0u, 0x00020000);
+  const unsigned ldcb = (unsigned)p.ldc * (unsigned)sizeof(T);
+  const unsigned img_off = (unsigned)((long)b * p.src_batch_stride * (long)sizeof(T));
+
+  // byte offsets of the halo chunks this thread stages (independent of the channel chunk)
+  unsigned h_off[NHL];
+#pragma unroll
+  for (int j = 0; j < NHL; ++j) {
+    const int idx = tid + 256 * j;
+    const int row = idx >> 3, ch = idx & 7;
+    const int hy = row / C::HWD, hx = row - hy * C::HWD;
+    const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+    const bool ok = idx < C::HROWS * 8 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    h_off[j] = ok ? img_off + (unsigned)(y * W + x) * ldcb + (unsigned)(ch * 16) : 0xFFFFFFFFu;
+  }
+  const int chunk = tid & 7, r0 = tid >> 3;
+  unsigned w_off[WR];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    const int n = n0 + r0 + 32 * i;
+    w_off[i] = n < p.Wrows ? (unsigned)(((long)n * p.ldw) * (long)sizeof(T)) + (unsigned)(chunk * 16) : 0xFFFFFFFFu;
+  }
+  // halo row of each output pixel this lane feeds to the MFMA (tap (0,0) position)
+  int hrow0[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int ml = wm * 64 + mi * 32 + l31;
+    hrow0[mi] = (ml / TW) * C::HWD + (ml % TW);
+  }
+
+  const int NC = p.Cin / BK, NS = NC * 9;
+  int l_tap = 0, l_cc = 0;  // load-side position in the (cc, tap) walk
+  int c_tap = 0, c_cc = 0;  // compute-side position
+
+  auto gloadW = [&](uint4 (&wr)[WR]) {
+    const unsigned k0b = (unsigned)(l_tap * p.Cin + l_cc * BK) * (unsigned)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+      wr[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[i], k0b, 0));
+    if (++l_tap == 9) { l_tap = 0; ++l_cc; }
+  };
+  auto lstoreW = [&](int buf, const uint4 (&wr)[WR]) {
+    char* ws = wt + buf * C::W_BYTES;
+#pragma unroll
+    for (int i = 0; i < WR; ++i) *reinterpret_cast<uint4*>(ws + lds_off(r0 + 32 * i, chunk)) = wr[i];
+  };
+  uint4 hreg[NHL];
+  auto hload = [&](int cc) {
+    const unsigned cb = (unsigned)(cc * BK) * (unsigned)sizeof(T);
+#pragma unroll
+    for (int j = 0; j < NHL; ++j)
+      hreg[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, h_off[j], cb, 0));
+  };
+  auto hstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < NHL; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < C::HROWS * 8) *reinterpret_cast<uint4*>(halo + lds_off(idx >> 3, idx & 7)) = hreg[j];
+    }
+  };
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int bb = 0; bb < MI; ++bb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][bb][r] = 0.f;
+
+  auto compute = [&](int buf) {
+    const char* ws = wt + buf * C::W_BYTES;
+    const int ky = c_tap / 3, kx = c_tap - ky * 3;
+    const int tapoff = ky * C::HWD + kx;
+    const char* xrow[MI];
+    int xsw[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int hr = hrow0[mi] + tapoff;
+      xrow[mi] = halo + hr * 128;
+      xsw[mi] = (hr >> 1) & 7;
+    }
+    uint4 xf[2][MI], wf[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) xf[0][mi] = *reinterpret_cast<const uint4*>(xrow[mi] + ((h ^ xsw[mi]) << 4));
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      wf[0][ni] = *reinterpret_cast<const uint4*>(ws + lds_off(wn * C::WN + ni * 32 + l31, h));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < 3) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          xf[(s + 1) & 1][mi] = *reinterpret_cast<const uint4*>(xrow[mi] + (((2 * (s + 1) + h) ^ xsw[mi]) << 4));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          wf[(s + 1) & 1][ni] =
+              *reinterpret_cast<const uint4*>(ws + lds_off(wn * C::WN + ni * 32 + l31, 2 * (s + 1) + h));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) Mma<T>::step(wf[s & 1][ni], xf[s & 1][mi], acc[ni][mi]);
+    }
+  };
+  // end of a step: publish the next weight tile; at a channel-chunk boundary swap in the prefetched halo
+  auto step_end = [&]() {
+    const bool boundary = (c_tap == 8) && (c_cc + 1 < NC);
+    __syncthreads();
+    if (boundary) {
+      hstore();
+      __syncthreads();
+    }
+    if (++c_tap == 9) { c_tap = 0; ++c_cc; }
+  };
+
+  uint4 wa[WR], wb[WR];
+  hload(0);
+  gloadW(wa);
+  if (NS > 1) gloadW(wb);
+  hstore();
+  lstoreW(0, wa);
+  __syncthreads();
+  for (int st = 0; st < NS; st += 2) {
+    if (c_tap == 0 && c_cc + 1 < NC) hload(c_cc + 1);
+    if (st + 2 < NS) gloadW(wa);
+    compute(0);
+    if (st + 1 < NS) lstoreW(1, wb);
+    step_end();
+    if (st + 1 >= NS) break;
+    if (c_tap == 0 && c_cc + 1 < NC) hload(c_cc + 1);
+    if (st + 3 < NS) gloadW(wb);
+    compute(1);
+    if (st + 2 < NS) lstoreW(0, wa);
+    step_end();
+  }
+
+  // ---- epilogue (same two-phase scheme as conv_gemm_kernel; no GEGLU / split-K here) ----
+  float* et = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int row = wm * 64 + mi * 32 + l31;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 o;
+        o.x = acc[ni][mi][4 * q + 0] * p.alpha; o.y = acc[ni][mi][4 * q + 1] * p.alpha;
+        o.z = acc[ni][mi][4 * q + 2] * p.alpha; o.w = acc[ni][mi][4 * q + 3] * p.alpha;
+        *reinterpret_cast<float4*>(et + row * C::EPI_LD + wn * C::WN + ni * 32 + 8 * q + 4 * h) = o;
+      }
+  }
+  __syncthreads();
+  constexpr int tpr = BN >> 3, rpp = 256 / tpr;
+  const int trow = tid / tpr, c8 = (tid - trow * tpr) * 8;
+  const int n = n0 + c8;
+  T* __restrict__ out = reinterpret_cast<T*>(p.out);
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+  const T* __restrict__ rowb = reinterpret_cast<const T*>(p.rowbias);
+  if (n < p.N) {
+    const int nvalid = min(8, p.N - n);
+    for (int row = trow; row < 128; row += rpp) {
+      const int py = row / TW, px = row - py * TW;
+      const int m = (b * H + ty0 + py) * W + tx0 + px;
+      float v[8];
+      const float4 a = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8);
+      const float4 b4 = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
+      epi_store8<T>(p, v, m, b, n, nvalid, out, res, rowb, p.bias);
     }
   }
 }
@@ -420,6 +668,19 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
       if (s >= 2) pl.splitk = s;
     }
   }
+  // 3x3 / stride 1 / no upsample on maps that tile by 4x32 or 8x16 pixels: LDS-halo kernel (tile 2 or 0 = BN 64 / 128)
+  pl.halo_tw = 0;
+  if (p.ks == 3 && p.stride == 1 && p.up == 0 && p.pad == 1 && batch == 1 && !geglu && pl.splitk == 1 &&
+      p.Ho == p.Hi && p.Wo == p.Wi && p.ldc >= p.Cin && env_int("AF_CONV_HALO", 1)) {
+    if (p.Wo % 32 == 0 && p.Ho % 4 == 0) pl.halo_tw = 32;
+    else if (p.Wo % 16 == 0 && p.Ho % 8 == 0) pl.halo_tw = 16;
+    if (pl.halo_tw) {
+      const long nb128 = (long)(p.M / 128) * ((p.N + 127) / 128), nb64 = (long)(p.M / 128) * ((p.N + 63) / 64);
+      const double c128 = (double)((nb128 + 255) / 256) * 128, c64 = (double)((nb64 + 255) / 256) * 64 / 0.9;
+      pl.tile = (n128 && c128 <= c64) ? 0 : 2;
+      if (!n128 && (p.N % 64) != 0) pl.tile = 2;
+    }
+  }
   const int ft = env_int("AF_GEMM_TILE", -1);
   if (ft >= 0 && ft < 4 && !(geglu && bn[ft] != 128)) pl.tile = ft;
   const int fs = env_int("AF_GEMM_SPLITK", -1);
@@ -440,6 +701,20 @@ static int launch_cfg(const ConvGemmParams& p, int batch, hipStream_t stream) {
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, 1, p.splitk > 1 ? p.splitk : batch);
   hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN>), grid, dim3(256), C::LDS_BYTES, stream, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+template <typename T, int TW, int BN> static int launch_halo(const ConvGemmParams& p, hipStream_t stream) {
+  using C = HaloCfg<TW, BN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, TW, BN>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    attr_set = true;
+  }
+  dim3 grid((p.M / 128) * ((p.N + BN - 1) / BN), 1, 1);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, TW, BN>), grid, dim3(256), C::LDS_BYTES, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -469,6 +744,12 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   AfProfScope prof(AF_K_CONV_GEMM, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K) * batch,
                    ((double)p.M * p.K / (p.ks * p.ks) + (double)p.N * p.K + (double)p.M * p.N) * batch * sizeof(T));
   int rc;
+  if (pl.halo_tw) {
+    const bool bn128 = pl.tile == 0 || pl.tile == 1;
+    if (pl.halo_tw == 32) rc = bn128 ? launch_halo<T, 32, 128>(p, stream) : launch_halo<T, 32, 64>(p, stream);
+    else rc = bn128 ? launch_halo<T, 16, 128>(p, stream) : launch_halo<T, 16, 64>(p, stream);
+    return rc;
+  }
   switch (pl.tile) {
     case 0: rc = launch_cfg<T, 128, 128>(p, batch, stream); break;
     case 1: rc = launch_cfg<T, 64, 128>(p, batch, stream); break;
