@@ -1,0 +1,70 @@
+"""Data-parallel sampling over the GPUs of one node.
+
+Samples of a batch never interact on the denoising path (GroupNorm statistics are per sample, attention is
+per sample and head; the CFG cond/uncond pair of a sample stays on one GPU), so the path shards by sample:
+one process per GPU, weights replicated, inputs sliced from globally seeded tensors so results do not depend
+on the world size, no communication during the 50 steps, and exactly ONE collective per batch: an all-gather
+of the decoded uint8 frames (RCCL over xGMI when the process group backend is "nccl"; "gloo" in CPU tests).
+The reference has no equivalent — it is single-process, single-GPU (scripts/stable_txt2img.py:238,342).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world() -> Tuple[int, int]:
+    """(rank, world_size); (0, 1) when torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(global_batch: int, rank: Optional[int] = None, world_size: Optional[int] = None) -> Tuple[int, int]:
+    """Contiguous [lo, hi) slice of the global batch owned by `rank`; the first (global_batch % world) ranks take
+    one extra sample, so any global batch is covered exactly once."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    base, extra = divmod(global_batch, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_batch(t: torch.Tensor, rank: Optional[int] = None, world_size: Optional[int] = None,
+                per_sample: int = 1) -> torch.Tensor:
+    """Slice dim 0 of a globally generated tensor; `per_sample` = rows per sample (16 for the layerwise context
+    [B*16, 77, 768], whose layer copies are adjacent per sample: embedding_manager.py:1342-1353)."""
+    if t.shape[0] % per_sample:
+        raise ValueError("dim 0 is not a multiple of per_sample")
+    lo, hi = shard_range(t.shape[0] // per_sample, rank, world_size)
+    return t[lo * per_sample:hi * per_sample]
+
+
+def gather_frames(frames: torch.Tensor, global_batch: Optional[int] = None) -> torch.Tensor:
+    """All-gather decoded frames [b_local, H, W, 3] (uint8) -> [global_batch, H, W, 3] on every rank, in global
+    sample order.  Equal shards use one all_gather_into_tensor; ragged shards pad to the largest shard."""
+    rank, w = world()
+    if w == 1:
+        return frames
+    b_local = frames.shape[0]
+    if global_batch is None:
+        n = torch.tensor([b_local], device=frames.device, dtype=torch.int64)
+        dist.all_reduce(n)
+        global_batch = int(n.item())
+    sizes = [shard_range(global_batch, r, w) for r in range(w)]
+    counts = [hi - lo for lo, hi in sizes]
+    if len(set(counts)) == 1:
+        out = torch.empty((global_batch,) + tuple(frames.shape[1:]), dtype=frames.dtype, device=frames.device)
+        dist.all_gather_into_tensor(out, frames.contiguous())
+        return out
+    bmax = max(counts)
+    padded = torch.zeros((bmax,) + tuple(frames.shape[1:]), dtype=frames.dtype, device=frames.device)
+    padded[:b_local] = frames
+    bufs = [torch.empty_like(padded) for _ in range(w)]
+    dist.all_gather(bufs, padded)
+    return torch.cat([bufs[r][:counts[r]] for r in range(w)], dim=0)

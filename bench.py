@@ -108,6 +108,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
     from adaface_amd import _lib
+    from adaface_amd.parallel import gather_frames, shard_batch
     from adaface_amd.synth import synth_context
     from ldm.models.diffusion.ddim import DDIMSampler
     lib = _lib.load()
@@ -117,21 +118,16 @@ def main():
     sampler = DDIMSampler(model)
     # global inputs generated from one seed on the host, sliced per rank (results independent of world size)
     g = torch.Generator().manual_seed(42)
-    x_T = torch.randn(world * B, 4, 64, 64, generator=g)[rank * B:(rank + 1) * B].to(device)
-    c_emb = synth_context(world * B, seed=100, device="cpu")[rank * B * 16:(rank + 1) * B * 16].to(device)
+    x_T = shard_batch(torch.randn(world * B, 4, 64, 64, generator=g), rank, world).to(device)
+    c_emb = shard_batch(synth_context(world * B, seed=100, device="cpu"), rank, world, per_sample=16).to(device)
     uc_emb = synth_context(B, seed=101, device=device, shared=True)
     c = model.get_learned_conditioning(c_emb)
     uc = model.get_learned_conditioning(uc_emb)
-    gathered = torch.empty(world * B, 512, 512, 3, dtype=torch.uint8, device=device) if world > 1 else None
-
     def step():
         samples, _ = sampler.sample(S=S, conditioning=c, batch_size=B, shape=[4, 64, 64], verbose=False,
                                     guidance_scale=[10.0, 4.0], unconditional_conditioning=uc, eta=0.0, x_T=x_T)
         frames = model.decode_first_stage_uint8(samples)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, frames)
-            return gathered
-        return frames
+        return gather_frames(frames, global_batch=world * B)  # one RCCL all-gather per batch (no-op at N=1)
 
     def fence():
         if world > 1:
