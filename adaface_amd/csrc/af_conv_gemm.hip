@@ -48,6 +48,16 @@ template <int BM, int BN> struct TileCfg {
   static constexpr int LDS_BYTES = (2 * TILE_BYTES > EPI_BYTES) ? 2 * TILE_BYTES : EPI_BYTES;
 };
 
+// LDS-DMA: 16 bytes per lane from a buffer resource straight into LDS at (wave-uniform base) + lane*16.
+// (The builtin only exists in the device pass; the host pass of this translation unit must not see it, or clang
+// silently drops the kernel's host stub.)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_base, unsigned voffset, unsigned soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_base, 16, voffset, soffset,
+                                           0, 0);
+#endif
+}
+
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
@@ -95,7 +105,7 @@ __device__ __forceinline__ void epi_store8(const ConvGemmParams& p, float (&v)[8
     }
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool DMA>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
   using C = TileCfg<BM, BN>;
   constexpr int EPC = 16 / sizeof(T);
@@ -133,6 +143,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       const_cast<T*>(reinterpret_cast<const T*>(p.W) + zb * p.bs_w), 0, (int)0xFFFFFFF0u, 0x00020000);
 
   const int chunk = tid & 7, r0 = tid >> 3;
+  // DMA variant: LDS-DMA writes lane-linearly (slot = lane&7 of row r0+32i), so the XOR swizzle moves to the
+  // SOURCE address: slot c' of row r receives data chunk c' ^ ((r>>1)&7) (bits 1-3 of r do not depend on i)
+  const int schunk = DMA ? (chunk ^ ((r0 >> 1) & 7)) : chunk;
   const int HoWo = p.Ho * p.Wo;
   const unsigned ldcb = (unsigned)p.ldc * (unsigned)sizeof(T);
 
@@ -151,14 +164,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     int ox = rem - oy * p.Wo;
     x_iy0[i] = oy * p.stride - p.pad;
     x_ix0[i] = ox * p.stride - p.pad;
-    x_off[i] = (unsigned)((long)b * p.src_batch_stride * (long)sizeof(T)) + (unsigned)(chunk * 16);
+    x_off[i] = (unsigned)((long)b * p.src_batch_stride * (long)sizeof(T)) + (unsigned)(schunk * 16);
     x_ok[i] = ok;
   }
   unsigned w_off[WR];
 #pragma unroll
   for (int i = 0; i < WR; ++i) {
     int n = n0 + r0 + 32 * i;
-    w_off[i] = n < p.Wrows ? (unsigned)(((long)n * p.ldw) * (long)sizeof(T)) + (unsigned)(chunk * 16) : 0xFFFFFFFFu;
+    w_off[i] = n < p.Wrows ? (unsigned)(((long)n * p.ldw) * (long)sizeof(T)) + (unsigned)(schunk * 16) : 0xFFFFFFFFu;
   }
 
   // K range of this block
@@ -246,23 +259,61 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     }
   };
 
-  // Two register sets: while tile kt is multiplied from LDS, tile kt+1 sits in one set (loaded a whole
-  // iteration ago, so its ds_write does not wait) and tile kt+2's loads are issued into the other.
-  uint4 xa[XR], wa[WR], xb[XR], wb[WR];
-  if (KT > 0) gload(xa, wa, kt_begin * BK);
-  if (KT > 1) gload(xb, wb, (kt_begin + 1) * BK);
-  if (KT > 0) lstore(0, xa, wa);
-  __syncthreads();
-  for (int kt = 0; kt < KT; kt += 2) {
-    if (kt + 2 < KT) gload(xa, wa, (kt_begin + kt + 2) * BK);
-    compute(0);
-    if (kt + 1 < KT) lstore(1, xb, wb);
+  if constexpr (!DMA) {
+    // Two register sets: while tile kt is multiplied from LDS, tile kt+1 sits in one set (loaded a whole
+    // iteration ago, so its ds_write does not wait) and tile kt+2's loads are issued into the other.
+    uint4 xa[XR], wa[WR], xb[XR], wb[WR];
+    if (KT > 0) gload(xa, wa, kt_begin * BK);
+    if (KT > 1) gload(xb, wb, (kt_begin + 1) * BK);
+    if (KT > 0) lstore(0, xa, wa);
     __syncthreads();
-    if (kt + 1 >= KT) break;
-    if (kt + 3 < KT) gload(xb, wb, (kt_begin + kt + 3) * BK);
-    compute(1);
-    if (kt + 2 < KT) lstore(0, xa, wa);
+    for (int kt = 0; kt < KT; kt += 2) {
+      if (kt + 2 < KT) gload(xa, wa, (kt_begin + kt + 2) * BK);
+      compute(0);
+      if (kt + 1 < KT) lstore(1, xb, wb);
+      __syncthreads();
+      if (kt + 1 >= KT) break;
+      if (kt + 3 < KT) gload(xb, wb, (kt_begin + kt + 3) * BK);
+      compute(1);
+      if (kt + 2 < KT) lstore(0, xa, wa);
+      __syncthreads();
+    }
+  } else {
+    // LDS-DMA staging (buffer_load ... lds): no VGPR round trip and no ds_write; tile kt+1 lands in the other
+    // buffer while tile kt is multiplied.  Out-of-range lanes (padding / tails) are written as zeros by the DMA.
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto gdma = [&](int buf, int k0) {
+      char* xs = smem + buf * C::TILE_BYTES + wv * 1024;
+      char* ws = xs + BM * 128;
+      const unsigned c0b = (unsigned)c0 * (unsigned)sizeof(T);
+#pragma unroll
+      for (int i = 0; i < XR; ++i) {
+        const int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
+        const bool ok = x_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        const unsigned pix = (unsigned)((iy >> p.up) * p.Ws + (ix >> p.up));
+        const unsigned vo = ok ? x_off[i] + pix * ldcb : 0xFFFFFFFFu;
+        lds_dma16(rs_x, xs + i * 4096, vo, c0b);
+      }
+      const unsigned k0b = (unsigned)k0 * (unsigned)sizeof(T);
+#pragma unroll
+      for (int i = 0; i < WR; ++i)
+        lds_dma16(rs_w, ws + i * 4096, w_off[i], k0b);
+      c0 += BK;
+      if (c0 >= p.Cin) {
+        c0 = 0;
+        if (++kx >= p.ks) { kx = 0; ++ky; }
+      }
+    };
+    if (KT > 0) gdma(0, kt_begin * BK);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < KT) gdma(cur ^ 1, (kt_begin + kt + 1) * BK);
+      compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 
   // ------------------------------- epilogue -------------------------------
@@ -689,20 +740,25 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
   return pl;
 }
 
-template <typename T, int BM, int BN>
-static int launch_cfg(const ConvGemmParams& p, int batch, hipStream_t stream) {
+template <typename T, int BM, int BN, bool DMA>
+static int launch_cfg2(const ConvGemmParams& p, int batch, hipStream_t stream) {
   using C = TileCfg<BM, BN>;
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN>),
+    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, DMA>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_set = true;
   }
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, 1, p.splitk > 1 ? p.splitk : batch);
-  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN>), grid, dim3(256), C::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, DMA>), grid, dim3(256), C::LDS_BYTES, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
+}
+template <typename T, int BM, int BN>
+static int launch_cfg(const ConvGemmParams& p, int batch, hipStream_t stream) {
+  static const int use_dma = env_int("AF_GEMM_DMA", 1);
+  return use_dma ? launch_cfg2<T, BM, BN, true>(p, batch, stream) : launch_cfg2<T, BM, BN, false>(p, batch, stream);
 }
 
 template <typename T, int TW, int BN> static int launch_halo(const ConvGemmParams& p, hipStream_t stream) {
