@@ -96,10 +96,13 @@ class UNetModel(HipModule):
             raise NotImplementedError("iter_type 'mix_hijk' (separate k/v contexts) is a training-time option")
         eng = self.engine(x.device)
         B = x.shape[0]
-        key = (context.data_ptr(), getattr(context, "_version", 0), tuple(context.shape), layerwise, B)
+        # Hoisted cross-attention K/V are cached per context TENSOR OBJECT: a reference to it is kept so that its
+        # id / storage cannot be recycled for another prompt while the cache is live (data_ptr alone is unsafe).
+        key = (id(context), getattr(context, "_version", 0), tuple(context.shape), layerwise, B)
         if key != self._ctx_key:
             eng.set_context(context.to(x.device), B, layerwise)
             object.__setattr__(self, "_ctx_key", key)
+            object.__setattr__(self, "_ctx_ref", context)
         out = eng.unet_forward(x, timesteps.to(x.device))
         if extra_info is not None:
             # the reference writes the (here empty) distillation capture into the caller's dict (:1031-1035)
