@@ -405,6 +405,249 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 }
 
 // ---------------------------------------------------------------------------
+// Wide tile: 256 x BN (BN = 128 or 256), 8 waves as 4(M) x 2(N), LDS-DMA staging only.
+//
+// The 128x128 / 4-wave structure tops out near 900 TFLOP/s (one barrier per 16 MFMAs, 64 B of L2->LDS traffic per
+// MFMA-clock at peak).  Doubling both tile edges halves the staged bytes per FLOP and puts 16-32 MFMAs per wave
+// between barriers; with LDS-DMA there is no VGPR staging, so the 128 accumulator registers of a 64x128 wave tile
+// fit.  Used for the big-M, big-N layers (GEGLU projections, fused QKV, up-sample convs, VAE).  Same gather, swizzle,
+// fused epilogues and XCD-aware grid as conv_gemm_kernel; the epilogue goes through LDS in 64/128-row slabs.
+// ---------------------------------------------------------------------------
+template <int BN> struct WideCfg {
+  static constexpr int BM = 256, NT = 512;
+  static constexpr int XR = BM / 64, WR = BN / 64;       // DMA instructions per thread per K tile
+  static constexpr int WM = 64, WN = BN / 2;
+  static constexpr int MI = 2, NI = WN / 32;
+  static constexpr int TILE_BYTES = (BM + BN) * 128;
+  static constexpr int EPI_LD = BN + 4;
+  static constexpr int EROWS = BN == 256 ? 64 : 128;     // rows per epilogue slab
+  static constexpr int EPI_BYTES = EROWS * EPI_LD * 4;
+  static constexpr int LDS_BYTES = (2 * TILE_BYTES > EPI_BYTES) ? 2 * TILE_BYTES : EPI_BYTES;
+};
+
+template <typename T, int BN>
+__global__ __launch_bounds__(512) void gemm_wide_kernel(const ConvGemmParams p) {
+  using C = WideCfg<BN>;
+  constexpr int BM = C::BM, BK = 128 / sizeof(T);
+  constexpr int XR = C::XR, WR = C::WR, MI = C::MI, NI = C::NI;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wm = wave & 3, wn = wave >> 2;
+
+  const int ntn = (p.N + BN - 1) / BN;
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int tm = wg / ntn, tn = wg - tm * ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const long zb = blockIdx.z;
+
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(reinterpret_cast<const T*>(p.src) + zb * p.bs_src), 0, (int)0xFFFFFFF0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(reinterpret_cast<const T*>(p.W) + zb * p.bs_w), 0, (int)0xFFFFFFF0u, 0x00020000);
+
+  const int chunk = tid & 7, r0 = tid >> 3;               // r0 in [0,64); rows r0 + 64*i
+  const int schunk = chunk ^ ((r0 >> 1) & 7);             // swizzle on the SOURCE side (LDS-DMA writes lane-linearly)
+  const int HoWo = p.Ho * p.Wo;
+  const unsigned ldcb = (unsigned)p.ldc * (unsigned)sizeof(T);
+
+  int x_iy0[XR], x_ix0[XR];
+  unsigned x_off[XR];
+  bool x_ok[XR];
+#pragma unroll
+  for (int i = 0; i < XR; ++i) {
+    int m = m0 + r0 + 64 * i;
+    bool ok = m < p.M;
+    int mm = ok ? m : 0;
+    int b = mm / HoWo;
+    int rem = mm - b * HoWo;
+    int oy = rem / p.Wo;
+    int ox = rem - oy * p.Wo;
+    x_iy0[i] = oy * p.stride - p.pad;
+    x_ix0[i] = ox * p.stride - p.pad;
+    x_off[i] = (unsigned)((long)b * p.src_batch_stride * (long)sizeof(T)) + (unsigned)(schunk * 16);
+    x_ok[i] = ok;
+  }
+  unsigned w_off[WR];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    int n = n0 + r0 + 64 * i;
+    w_off[i] = n < p.Wrows ? (unsigned)(((long)n * p.ldw) * (long)sizeof(T)) + (unsigned)(schunk * 16) : 0xFFFFFFFFu;
+  }
+
+  const int KT = p.K / BK;
+  int ky = 0, kx = 0, c0 = 0;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto gdma = [&](int buf, int k0) {
+    char* xs = smem + buf * C::TILE_BYTES + wv * 1024;
+    char* ws = xs + BM * 128;
+    const unsigned c0b = (unsigned)c0 * (unsigned)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      const int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
+      const bool ok = x_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      const unsigned pix = (unsigned)((iy >> p.up) * p.Ws + (ix >> p.up));
+      const unsigned vo = ok ? x_off[i] + pix * ldcb : 0xFFFFFFFFu;
+      lds_dma16(rs_x, xs + i * 8192, vo, c0b);
+    }
+    const unsigned k0b = (unsigned)k0 * (unsigned)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < WR; ++i) lds_dma16(rs_w, ws + i * 8192, w_off[i], k0b);
+    c0 += BK;
+    if (c0 >= p.Cin) {
+      c0 = 0;
+      if (++kx >= p.ks) { kx = 0; ++ky; }
+    }
+  };
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  auto compute = [&](int buf) {
+    const char* xs = smem + buf * C::TILE_BYTES;
+    const char* ws = xs + BM * 128;
+    // fragment double buffering only where the register budget allows (BN = 128); at BN = 256 the 128 accumulator
+    // registers leave room for one fragment set and the two waves per SIMD cover the LDS latency for each other
+    constexpr int NFB = (BN == 256) ? 1 : 2;
+    uint4 xf[NFB][MI], wf[NFB][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      xf[0][mi] = *reinterpret_cast<const uint4*>(xs + lds_off(wm * 64 + mi * 32 + l31, h));
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      wf[0][ni] = *reinterpret_cast<const uint4*>(ws + lds_off(wn * C::WN + ni * 32 + l31, h));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (NFB == 2 && s < 3) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          xf[(s + 1) % NFB][mi] =
+              *reinterpret_cast<const uint4*>(xs + lds_off(wm * 64 + mi * 32 + l31, 2 * (s + 1) + h));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          wf[(s + 1) % NFB][ni] =
+              *reinterpret_cast<const uint4*>(ws + lds_off(wn * C::WN + ni * 32 + l31, 2 * (s + 1) + h));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) Mma<T>::step(wf[s % NFB][ni], xf[s % NFB][mi], acc[ni][mi]);
+      if (NFB == 1 && s < 3) {
+        // keep hipcc from hoisting all 24 fragment reads of the K tile above the MFMAs (it then spills them)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          xf[0][mi] = *reinterpret_cast<const uint4*>(xs + lds_off(wm * 64 + mi * 32 + l31, 2 * (s + 1) + h));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          wf[0][ni] = *reinterpret_cast<const uint4*>(ws + lds_off(wn * C::WN + ni * 32 + l31, 2 * (s + 1) + h));
+      }
+    }
+  };
+
+  if (KT > 0) gdma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) gdma(cur ^ 1, (kt + 1) * BK);
+    compute(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue in slabs of EROWS rows through LDS ----
+  float* et = reinterpret_cast<float*>(smem);
+  const bool geglu = p.epilogue == AF_EPI_GEGLU;
+  const int BNo = geglu ? BN / 2 : BN;
+  const int tpr = BNo >> 3, rpp = 512 / tpr;
+  const int trow = tid / tpr, c8 = (tid - trow * tpr) * 8;
+  const int ncol0 = geglu ? (n0 >> 1) : n0;
+  const int Nvalid = geglu ? (p.N >> 1) : p.N;
+  const int n = ncol0 + c8;
+  T* __restrict__ out = reinterpret_cast<T*>(p.out) + zb * p.bs_out;
+  const T* __restrict__ res = p.residual ? reinterpret_cast<const T*>(p.residual) + zb * p.bs_res : nullptr;
+  const T* __restrict__ rowb = reinterpret_cast<const T*>(p.rowbias);
+  const float* __restrict__ bias = geglu ? nullptr : p.bias;
+  constexpr int NSLAB = BM / C::EROWS, WPS = C::EROWS / 64;  // wave rows per slab
+#pragma unroll 1
+  for (int slab = 0; slab < NSLAB; ++slab) {
+    if (wm / WPS == slab) {
+      const int rbase = (wm % WPS) * 64;
+      if (geglu) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int row = rbase + mi * 32 + l31;
+#pragma unroll
+          for (int g = 0; g < NI / 2; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int j = 8 * q + 4 * h;
+              const int nv = n0 + wn * C::WN + g * 64 + j;  // packed row of the value; gate = +32
+              float4 o;
+              float* op = reinterpret_cast<float*>(&o);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float val = acc[2 * g][mi][4 * q + e];   // alpha is 1 for every GEGLU projection
+                float gat = acc[2 * g + 1][mi][4 * q + e];
+                if (p.bias) { val += p.bias[nv + e]; gat += p.bias[nv + 32 + e]; }
+                op[e] = val * gelu_erf_f(gat);
+              }
+              *reinterpret_cast<float4*>(et + row * C::EPI_LD + wn * (C::WN / 2) + g * 32 + j) = o;
+            }
+        }
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int row = rbase + mi * 32 + l31;
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              // raw accumulators; alpha is applied after the LDS transpose (multiplying here makes hipcc
+              // materialise all 128 scaled values at once and spill)
+              float4 o;
+              o.x = acc[ni][mi][4 * q + 0]; o.y = acc[ni][mi][4 * q + 1];
+              o.z = acc[ni][mi][4 * q + 2]; o.w = acc[ni][mi][4 * q + 3];
+              *reinterpret_cast<float4*>(et + row * C::EPI_LD + wn * C::WN + ni * 32 + 8 * q + 4 * h) = o;
+            }
+        }
+      }
+    }
+    __syncthreads();
+    if (n < Nvalid) {
+      const int nvalid = min(8, Nvalid - n);
+      for (int row = trow; row < C::EROWS; row += rpp) {
+        const int m = m0 + slab * C::EROWS + row;
+        if (m >= p.M) break;
+        float v[8];
+        const float4 a = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8);
+        const float4 b4 = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
+        if (!geglu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+        }
+        epi_store8<T>(p, v, m, rowb ? m / HoWo : 0, n, nvalid, out, res, rowb, bias);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with an LDS-resident input halo.
 //
 // The implicit-GEMM kernel above re-gathers every input pixel 9 times (once per filter tap); at the 64x64 and
@@ -732,8 +975,18 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
       if (!n128 && (p.N % 64) != 0) pl.tile = 2;
     }
   }
+  // wide 8-wave tiles (experimental, off by default: with the simple 2-barrier pipeline they measured 5-15 % slower
+  // than 128x128 on every SD-1.5 shape and 2.6x slower on GEGLU, whose epilogue serialises over the row slabs)
+  if (!pl.halo_tw && pl.splitk == 1 && env_int("AF_GEMM_WIDE", 0)) {
+    const long tm256 = (p.M + 255) / 256;
+    const long nb256 = tm256 * ((p.N + 255) / 256) * batch, nb128 = tm256 * ((p.N + 127) / 128) * batch;
+    const double waste256 = (double)((p.N + 255) / 256 * 256) / p.N, waste128 = (double)((p.N + 127) / 128 * 128) / p.N;
+    if (p.N >= 512 && nb256 >= 512 && waste256 <= 1.07) pl.tile = 5;
+    else if (p.N >= 256 && nb128 >= 512 && waste128 <= 1.07) pl.tile = 4;
+  }
   const int ft = env_int("AF_GEMM_TILE", -1);
   if (ft >= 0 && ft < 4 && !(geglu && bn[ft] != 128)) pl.tile = ft;
+  if ((ft == 4 || ft == 5) && !pl.halo_tw && pl.splitk == 1) pl.tile = ft;
   const int fs = env_int("AF_GEMM_SPLITK", -1);
   if (fs >= 1 && batch == 1 && !geglu) pl.splitk = fs > KT ? KT : fs;
   if (pl.splitk > 1) pl.ws_bytes = (size_t)pl.splitk * p.M * p.N * sizeof(float);
@@ -759,6 +1012,20 @@ template <typename T, int BM, int BN>
 static int launch_cfg(const ConvGemmParams& p, int batch, hipStream_t stream) {
   static const int use_dma = env_int("AF_GEMM_DMA", 1);
   return use_dma ? launch_cfg2<T, BM, BN, true>(p, batch, stream) : launch_cfg2<T, BM, BN, false>(p, batch, stream);
+}
+
+template <typename T, int BN> static int launch_wide(const ConvGemmParams& p, int batch, hipStream_t stream) {
+  using C = WideCfg<BN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<T, BN>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    attr_set = true;
+  }
+  dim3 grid(((p.M + 255) / 256) * ((p.N + BN - 1) / BN), 1, batch);
+  hipLaunchKernelGGL((gemm_wide_kernel<T, BN>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
 }
 
 template <typename T, int TW, int BN> static int launch_halo(const ConvGemmParams& p, hipStream_t stream) {
@@ -807,6 +1074,8 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
     return rc;
   }
   switch (pl.tile) {
+    case 4: rc = launch_wide<T, 128>(p, batch, stream); break;
+    case 5: rc = launch_wide<T, 256>(p, batch, stream); break;
     case 0: rc = launch_cfg<T, 128, 128>(p, batch, stream); break;
     case 1: rc = launch_cfg<T, 64, 128>(p, batch, stream); break;
     case 2: rc = launch_cfg<T, 128, 64>(p, batch, stream); break;
