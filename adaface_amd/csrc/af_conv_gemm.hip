@@ -1010,7 +1010,11 @@ static int launch_cfg2(const ConvGemmParams& p, int batch, hipStream_t stream) {
 }
 template <typename T, int BM, int BN>
 static int launch_cfg(const ConvGemmParams& p, int batch, hipStream_t stream) {
-  static const int use_dma = env_int("AF_GEMM_DMA", 1);
+  // LDS-DMA staging wins on deep-K problems (fewer VGPRs, no ds_write); with few K tiles the 2-deep register
+  // prefetch hides the first loads better.  AF_GEMM_DMA = 0 / 1 forces one variant, default: by K depth.
+  static const int force = env_int("AF_GEMM_DMA", -1);
+  const int kt_per_slice = p.K / (128 / (int)sizeof(T)) / (p.splitk > 1 ? p.splitk : 1);
+  const bool use_dma = force >= 0 ? force != 0 : kt_per_slice >= 32;
   return use_dma ? launch_cfg2<T, BM, BN, true>(p, batch, stream) : launch_cfg2<T, BM, BN, false>(p, batch, stream);
 }
 
