@@ -171,6 +171,7 @@ struct ConvGemmParams {
   // split-K (set by the launcher): K slices write fp32 slabs ws[splitk][M][N]
   int splitk;
   void* ws;
+  int group_m;            // grouped tile ordering (set by the launcher): M tiles swept per N tile
 };
 
 struct AfGemmPlan {
@@ -178,6 +179,7 @@ struct AfGemmPlan {
   int splitk;       // >= 1
   size_t ws_bytes;  // fp32 slab workspace needed when splitk > 1
   int halo_tw;      // 0 = implicit-GEMM kernel; 16 / 32 = LDS-halo 3x3 kernel with that patch width
+  int group_m;      // grouped tile ordering: M tiles swept per N tile
 };
 
 struct AttnParams {
