@@ -51,12 +51,27 @@ template <typename T, int DH> struct AttnCfg {
   // a free padding column d = DH of the V tile holds 1.0 for valid keys: row DH of O^T is then the softmax
   // denominator, summed by the MFMA instead of 32 VALU adds per tile (bf16 only; needs DH % 32 != 0)
   static constexpr bool ONES = BF && (DH % 32) != 0;
+  // a free padding slot d = DH in the QK^T K-dimension (dh = 40: 80 -> 96 bytes) carries "1.0" on the K side and
+  // "-m_ref" (the per-query running softmax reference, kept bf16-representable) on the Q side: the MFMA then returns
+  // s - m_ref directly and the 32 v_sub per tile disappear; m_ref moves only when a tile's maximum exceeds it.
+  // (measured on MI355X: the two code paths raise dh=40 from 152 to 190 VGPRs, 3 -> 2 waves per SIMD, and the kernel
+  //  gets 24 % slower, so the variant is compiled out; kept for the next round's register work)
+  static constexpr bool MREF = false && BF && ((DH * 2) % 32) != 0;
+  static constexpr int MREF_STEP = (DH * 2) / 32, MREF_HALF = ((DH * 2) % 32) / 16, MREF_ELEM = (((DH * 2) % 32) % 16) / 2;
 };
 
 __device__ __forceinline__ float xhalf_max(float v) {
   const unsigned b = __builtin_bit_cast(unsigned, v);
   const u32x2 r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
   return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
+// smallest bf16-representable value >= x, as fp32
+__device__ __forceinline__ float bf16_ceil(float x) {
+  unsigned u = __builtin_bit_cast(unsigned, x);
+  if (x > 0.f && (u & 0xFFFFu)) u += 0x10000u;  // positive: bump; negative: truncation already moves up
+  u &= 0xFFFF0000u;
+  return __builtin_bit_cast(float, u);
 }
 
 // one v_max3_f32 (plain fmaxf on MFMA outputs makes hipcc insert a canonicalising v_max per operand)
@@ -107,7 +122,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   for (int d = 0; d < DB; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = C::MREF ? 0.f : -INFINITY, l_run = 0.f;  // MREF: m_run is the bf16-representable reference
 
   // ---- staging helpers ----
   uint4 kreg[NLD], vreg[NLD];
@@ -155,6 +170,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 
   const int nt = (p.Nk + 63) / 64;
   __syncthreads();  // zero fill done
+  if constexpr (C::MREF) {
+    if (tid < 64 * C::NBUF)
+      *reinterpret_cast<unsigned short*>(smem + (tid >> 6) * C::TILE + (tid & 63) * KROW + DH * 2) = 0x3F80;
+  }
   gload(0);
   lstore(0);
   __syncthreads();
@@ -186,32 +205,76 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
           if (t0 + 32 * kb + acc_row(r, h) >= p.Nk) s[kb][r] = -INFINITY;
     }
     // ---- online softmax (per lane = per query; the two lane halves hold disjoint keys) ----
-    float mx = max3f(s[0][0], s[1][0], s[0][1]);
-    mx = max3f(mx, s[1][1], s[0][2]);
+    // tile maximum: four independent max3 chains, then across the two lane halves
+    float mxa = max3f(s[0][0], s[0][1], s[0][2]), mxb = max3f(s[0][8], s[0][9], s[0][10]);
+    float mxc = max3f(s[1][0], s[1][1], s[1][2]), mxd = max3f(s[1][8], s[1][9], s[1][10]);
+    mxa = max3f(mxa, s[0][3], s[0][4]); mxb = max3f(mxb, s[0][11], s[0][12]);
+    mxc = max3f(mxc, s[1][3], s[1][4]); mxd = max3f(mxd, s[1][11], s[1][12]);
+    mxa = max3f(mxa, s[0][5], s[0][6]); mxb = max3f(mxb, s[0][13], s[0][14]);
+    mxc = max3f(mxc, s[1][5], s[1][6]); mxd = max3f(mxd, s[1][13], s[1][14]);
+    mxa = max3f(mxa, s[0][7], s[0][15]); mxc = max3f(mxc, s[1][7], s[1][15]);
+    float mx = max3f(mxa, mxb, mxc);
+    mx = xhalf_max(fmaxf(mx, mxd));
+    if constexpr (C::MREF) {
+      // s already holds score - m_ref.  The reference moves (rarely after the first tiles) when mx > 0.
+      const bool move = (t == 0) || mx > 0.f;
+      if (__builtin_amdgcn_ballot_w64(move) != 0) {
+        const float m_new = move ? bf16_ceil(m_run + mx) : m_run;
+        const float delta = m_new - m_run;  // exact: both are bf16 values
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        float psum = 0.f;
 #pragma unroll
-    for (int r = 2; r < 15; r += 2) {
-      mx = max3f(mx, s[1][r], s[0][r + 1]);
-      mx = max3f(mx, s[1][r + 1], (r + 2 < 16) ? s[0][r + 2] : s[1][r + 1]);
-    }
-    mx = xhalf_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float psum = 0.f;
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+          for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(s[kb][r] - delta);
+            s[kb][r] = pv;
+            if constexpr (!C::ONES) psum += pv;
+          }
+        if constexpr (!C::ONES) l_run = l_run * alpha + psum;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
-        s[kb][r] = pv;
-        if constexpr (!C::ONES) psum += pv;
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        m_run = m_new;
+        if (h == C::MREF_HALF) {  // refresh the -m_ref slot of this lane's Q fragment
+          Vec16<T> v;
+          v.u = qf[C::MREF_STEP];
+          v.e[C::MREF_ELEM] = from_f32<T>(-m_new);
+          qf[C::MREF_STEP] = v.u;
+        }
+      } else {
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(s[kb][r]);
+            s[kb][r] = pv;
+            if constexpr (!C::ONES) psum += pv;
+          }
+        if constexpr (!C::ONES) l_run += psum;
       }
-    if constexpr (!C::ONES) l_run = l_run * alpha + psum;
-    m_run = m_new;
-    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {  // rescale only when some lane's max moved
+    } else {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float psum = 0.f;
 #pragma unroll
-      for (int d = 0; d < DB; ++d)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+          s[kb][r] = pv;
+          if constexpr (!C::ONES) psum += pv;
+        }
+      if constexpr (!C::ONES) l_run = l_run * alpha + psum;
+      m_run = m_new;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {  // rescale only when some lane's max moved
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      }
     }
 
     // ---- O^T += V^T P^T ----
