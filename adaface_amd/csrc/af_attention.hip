@@ -205,9 +205,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
           if (t0 + 32 * kb + acc_row(r, h) >= p.Nk) s[kb][r] = -INFINITY;
     }
     // ---- online softmax (per lane = per query; the two lane halves hold disjoint keys) ----
-    // tile maximum: four independent max3 chains, then across the two lane halves
-    float mxa = max3f(s[0][0], s[0][1], s[0][2]), mxb = max3f(s[0][8], s[0][9], s[0][10]);
-    float mxc = max3f(s[1][0], s[1][1], s[1][2]), mxd = max3f(s[1][8], s[1][9], s[1][10]);
+    // tile maximum: four independent max3 chains, then across the two lane halves.  The chain heads read MFMA
+    // results from inline asm: hipcc inserts no MFMA-result wait states for an asm statement (cdna guide 5.7 item 2),
+    // and a too-early read returns stale registers (seen as run-to-run differences), so they sit behind an s_nop.
+    float mxa, mxb, mxc, mxd;
+    asm("s_nop 15\n\t"
+        "v_max3_f32 %0, %4, %5, %6\n\t"
+        "v_max3_f32 %1, %7, %8, %9\n\t"
+        "v_max3_f32 %2, %10, %11, %12\n\t"
+        "v_max3_f32 %3, %13, %14, %15"
+        : "=&v"(mxa), "=&v"(mxb), "=&v"(mxc), "=&v"(mxd)
+        : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][8]), "v"(s[0][9]), "v"(s[0][10]), "v"(s[1][0]),
+          "v"(s[1][1]), "v"(s[1][2]), "v"(s[1][8]), "v"(s[1][9]), "v"(s[1][10]));
     mxa = max3f(mxa, s[0][3], s[0][4]); mxb = max3f(mxb, s[0][11], s[0][12]);
     mxc = max3f(mxc, s[1][3], s[1][4]); mxd = max3f(mxd, s[1][11], s[1][12]);
     mxa = max3f(mxa, s[0][5], s[0][6]); mxb = max3f(mxb, s[0][13], s[0][14]);

@@ -775,31 +775,42 @@ static int unet_forward_impl(af_handle* h, hipStream_t s, const float* x_dev, co
   if (!R.dry) AF_TRY(DISPATCH(dt, af_launch_silu<bf16>(e2.p, e2.p, (long)Bf * ted, s), af_launch_silu<float>(e2.p, e2.p, (long)Bf * ted, s)));
   AF_TRY(R.conv(h->emb_all, e2, emb_all, 1, 0, nullptr, nullptr, 0));
 
-  auto run_block = [&](const UBlock& ub, Act hcur, Act& result) -> int {
-    for (auto& l : ub.layers) {
+  // `final_out` (optional): a pre-assigned view for the block's last layer (zero-copy skip concat, see below)
+  auto run_block = [&](const UBlock& ub, Act hcur, Act& result, const Act* final_out) -> int {
+    for (size_t li = 0; li < ub.layers.size(); ++li) {
+      const LayerRef& l = ub.layers[li];
+      const bool use_final = final_out && li + 1 == ub.layers.size();
       Act out;
+      auto new_act = [&](int Hh, int Ww, int Cc) -> Act {
+        if (use_final) {
+          Act v = *final_out;
+          if (v.H != Hh || v.W != Ww || v.C != Cc) v.p = nullptr;  // plan mismatch -> reported by check()
+          return v;
+        }
+        return R.alloc_act(Bf, Hh, Ww, Cc);
+      };
       switch (l.kind) {
         case L_CONV_IN: {
-          out = R.alloc_act(Bf, hcur.H, hcur.W, mc);
+          out = new_act(hcur.H, hcur.W, mc);
           Act xin = hcur;
           xin.C = h->conv_in.cin;  // logical channels; ld carries the padding
           AF_TRY(R.conv(h->conv_in, xin, out, 1, 0, nullptr, nullptr, 0));
         } break;
         case L_RES: {
           const ResBlockW& w = h->res[l.idx];
-          out = R.alloc_act(Bf, hcur.H, hcur.W, w.cout);
+          out = new_act(hcur.H, hcur.W, w.cout);
           AF_TRY(run_resblock(R, w, hcur, out, emb_all.p, emb_all.ld));
         } break;
         case L_XFMR: {
-          out = R.alloc_act(Bf, hcur.H, hcur.W, hcur.C);
+          out = new_act(hcur.H, hcur.W, hcur.C);
           AF_TRY(run_xfmr(R, h->xf[l.idx], hcur, out));
         } break;
         case L_DOWN: {
-          out = R.alloc_act(Bf, hcur.H / 2, hcur.W / 2, hcur.C);
+          out = new_act(hcur.H / 2, hcur.W / 2, hcur.C);
           AF_TRY(R.conv(h->updown[l.idx], hcur, out, 2, 0, nullptr, nullptr, 0));
         } break;
         case L_UP: {
-          out = R.alloc_act(Bf, hcur.H * 2, hcur.W * 2, hcur.C);
+          out = new_act(hcur.H * 2, hcur.W * 2, hcur.C);
           AF_TRY(R.conv(h->updown[l.idx], hcur, out, 1, 1, nullptr, nullptr, 0));
         } break;
       }
@@ -809,29 +820,71 @@ static int unet_forward_impl(af_handle* h, hipStream_t s, const float* x_dev, co
     return 0;
   };
 
-  std::vector<Act> hs;
+  // ---- zero-copy skip concatenation ----
+  // h = cat([h, hs.pop()], dim=1) (openaimodel.py:1018-1019) needs no copy: every tensor that will be one half of a
+  // concatenation is produced straight into its half of a pre-allocated [.., C_h + C_skip] buffer (all kernels take
+  // a pixel stride).  Shapes follow statically from the block structure.
+  struct Shp { int C, H, W; };
+  auto out_shape = [&](const UBlock& ub, Shp in) -> Shp {
+    for (auto& l : ub.layers) {
+      if (l.kind == L_CONV_IN) in.C = mc;
+      else if (l.kind == L_RES) in.C = h->res[l.idx].cout;
+      else if (l.kind == L_DOWN) { in.H /= 2; in.W /= 2; }
+      else if (l.kind == L_UP) { in.H *= 2; in.W *= 2; }
+    }
+    return in;
+  };
+  const int n_in = (int)h->input_blocks.size(), n_out = (int)h->output_blocks.size();
+  std::vector<Shp> shp_in(n_in);
+  Shp cur = {c.in_channels, H, W};
+  for (int i = 0; i < n_in; ++i) shp_in[i] = cur = out_shape(h->input_blocks[i], cur);
+  Shp hshape = out_shape(h->middle_block, cur);
+  std::vector<Act> cat(n_out);
+  std::vector<int> ch_h(n_out);
+  for (int j = 0; j < n_out; ++j) {
+    const Shp sk = shp_in[n_in - 1 - j];
+    if (j >= n_in || sk.H != hshape.H || sk.W != hshape.W) {
+      af_set_error_msg("unet: skip connection %d does not match (%dx%d vs %dx%d)", j, sk.H, sk.W, hshape.H, hshape.W);
+      return AF_ERR_INVALID;
+    }
+    ch_h[j] = hshape.C;
+    cat[j] = R.alloc_act(Bf, hshape.H, hshape.W, hshape.C + sk.C);
+    AF_TRY(R.check(cat[j]));
+    hshape = out_shape(h->output_blocks[j], Shp{hshape.C + sk.C, hshape.H, hshape.W});
+  }
+  auto view = [&](const Act& full, int off, int Cc) -> Act {
+    Act v = full;
+    v.p = R.elem_ptr(full.p, off);
+    v.C = Cc;
+    return v;  // ld stays the full row length
+  };
+
   Act hcur = x;
-  for (auto& ub : h->input_blocks) {
+  for (int i = 0; i < n_in; ++i) {
+    const int j = n_in - 1 - i;  // the output block that will consume this skip
     Act o;
-    AF_TRY(run_block(ub, hcur, o));
+    if (j < n_out) {
+      const Act dst = view(cat[j], ch_h[j], shp_in[i].C);
+      AF_TRY(run_block(h->input_blocks[i], hcur, o, &dst));
+    } else {
+      AF_TRY(run_block(h->input_blocks[i], hcur, o, nullptr));
+    }
     hcur = o;
-    hs.push_back(hcur);
   }
   {
     Act o;
-    AF_TRY(run_block(h->middle_block, hcur, o));
+    const Act dst = view(cat[0], 0, ch_h[0]);
+    AF_TRY(run_block(h->middle_block, hcur, o, n_out > 0 ? &dst : nullptr));
     hcur = o;
   }
-  for (auto& ub : h->output_blocks) {
-    Act skip = hs.back();
-    hs.pop_back();
-    // h = cat([h, hs.pop()], dim=1)  (openaimodel.py:1018-1019)
-    Act cat = R.alloc_act(Bf, hcur.H, hcur.W, hcur.C + skip.C);
-    AF_TRY(R.check(cat));
-    AF_TRY(R.copy_channels(hcur, cat, 0));
-    AF_TRY(R.copy_channels(skip, cat, hcur.C));
+  for (int j = 0; j < n_out; ++j) {
     Act o;
-    AF_TRY(run_block(ub, cat, o));
+    if (j + 1 < n_out) {
+      const Act dst = view(cat[j + 1], 0, ch_h[j + 1]);
+      AF_TRY(run_block(h->output_blocks[j], cat[j], o, &dst));
+    } else {
+      AF_TRY(run_block(h->output_blocks[j], cat[j], o, nullptr));
+    }
     hcur = o;
   }
   // out: GroupNorm32 -> SiLU -> conv3x3 (openaimodel.py:693-697)

@@ -13,6 +13,7 @@
 //   gn_apply    grid (chunks, B): y = (x-mean)*rstd*gamma+beta, optional SiLU
 //   layernorm   one wave per row, row held in registers, two-pass variance
 #include "af_common.h"
+#include <cstdlib>
 
 #define GN_GROUPS 32
 #define GN_MAX_C 2560
@@ -130,17 +131,44 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                                                         const float* __restrict__ stats,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int silu,
-                                                        T* __restrict__ y, long y_batch_stride, int ldy) {
+                                                        T* __restrict__ y, long y_batch_stride, int ldy,
+                                                        const float* __restrict__ partial, int nchunk, double count,
+                                                        float eps) {
   constexpr int EPC = 16 / sizeof(T);
   __shared__ float s_a[GN_MAX_C];
   __shared__ float s_b[GN_MAX_C];
+  __shared__ double s_ra[256], s_rq[256];
+  __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int cpg = Cn / GN_GROUPS;
+  if (partial) {
+    // finalize folded in (few chunks): every block combines its sample's partial sums itself, in the same fixed
+    // order as gn_finalize_kernel, so the statistics are bitwise identical across blocks and launches
+    const int g = tid & 31, sl = tid >> 5;
+    double a = 0.0, q = 0.0;
+    for (int c = sl; c < nchunk; c += 8) {
+      const float* src = partial + (((long)b * nchunk + c) * GN_GROUPS + g) * 2;
+      a += (double)src[0];
+      q += (double)src[1];
+    }
+    s_ra[tid] = a;
+    s_rq[tid] = q;
+    __syncthreads();
+    if (tid < 32) {
+      for (int s2 = 1; s2 < 8; ++s2) { a += s_ra[tid + 32 * s2]; q += s_rq[tid + 32 * s2]; }
+      const double mean = a / count;
+      double var = q / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mean[tid] = (float)mean;
+      s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+  }
   for (int c = tid; c < Cn; c += 256) {
     const int g = c / cpg;
-    const float mean = stats[((long)b * GN_GROUPS + g) * 2 + 0];
-    const float rstd = stats[((long)b * GN_GROUPS + g) * 2 + 1];
+    const float mean = partial ? s_mean[g] : stats[((long)b * GN_GROUPS + g) * 2 + 0];
+    const float rstd = partial ? s_rstd[g] : stats[((long)b * GN_GROUPS + g) * 2 + 1];
     const float a = gamma[c] * rstd;
     s_a[c] = a;
     s_b[c] = beta[c] - mean * a;
@@ -262,11 +290,13 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
   float* stats = partial + (size_t)B * nchunk * GN_GROUPS * 2;
   hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nchunk, B), dim3(256), 0, stream,
                      reinterpret_cast<const T*>(x), x_bs, ldx, HW, Cn, P, partial, nchunk);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, partial, nchunk,
-                     (double)HW * (double)(Cn / GN_GROUPS), eps, stats);
+  const double count = (double)HW * (double)(Cn / GN_GROUPS);
+  static const bool fold_ok = !(getenv("AF_GN_FOLD") && atoi(getenv("AF_GN_FOLD")) == 0);
+  const bool fold = fold_ok && nchunk <= 64;  // few chunks: the apply blocks finalize the statistics themselves
+  if (!fold) hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, partial, nchunk, count, eps, stats);
   hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nchunk, B), dim3(256), 0, stream,
                      reinterpret_cast<const T*>(x), x_bs, ldx, HW, Cn, P, stats, gamma, beta, silu,
-                     reinterpret_cast<T*>(y), y_bs, ldy);
+                     reinterpret_cast<T*>(y), y_bs, ldy, fold ? partial : nullptr, nchunk, count, eps);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
