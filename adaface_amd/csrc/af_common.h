@@ -172,6 +172,7 @@ struct ConvGemmParams {
   int splitk;
   void* ws;
   int group_m;            // grouped tile ordering (set by the launcher): M tiles swept per N tile
+  int dbg_nobarrier;      // diagnostic: skip main-loop barriers (wrong results; measures barrier cost)
 };
 
 struct AfGemmPlan {

@@ -811,10 +811,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
   // end of a step: publish the next weight tile; at a channel-chunk boundary swap in the prefetched halo
   auto step_end = [&]() {
     const bool boundary = (c_tap == 8) && (c_cc + 1 < NC);
-    __syncthreads();
+    if (!p.dbg_nobarrier) __syncthreads();
     if (boundary) {
       hstore();
-      __syncthreads();
+      if (!p.dbg_nobarrier) __syncthreads();
     }
     if (++c_tap == 9) { c_tap = 0; ++c_cc; }
   };
@@ -1093,6 +1093,7 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   p.splitk = pl.splitk;
   p.ws = ws;
   p.group_m = pl.group_m > 0 ? pl.group_m : 1;
+  p.dbg_nobarrier = env_int("AF_DEBUG_NOBARRIER", 0);  // timing diagnostic only: results are WRONG when set
   AfProfScope prof(AF_K_CONV_GEMM, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K) * batch,
                    ((double)p.M * p.K / (p.ks * p.ks) + (double)p.N * p.K + (double)p.M * p.N) * batch * sizeof(T));
   int rc;
