@@ -58,6 +58,7 @@ _SIGS = [
     ("af_unet_forward", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("af_ddim_step", C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, _P, _P, _P]),
+    ("af_lincomb", C.c_int, [_P, C.c_int64, _P, C.c_float, _P, C.c_float, _P, C.c_float, _P, C.c_float, C.c_int, _P]),
     ("af_vae_decode", C.c_int, [_P, _P, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("af_to_uint8", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("af_arena_bytes", C.c_int64, [_P]),

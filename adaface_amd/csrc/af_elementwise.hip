@@ -121,6 +121,27 @@ __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __res
   }
 }
 
+// out = w0*x0 + w1*x1 + w2*x2 + w3*x3 (unused inputs NULL), fp32.  mode 1: out = x1 + w0*(x0 - x1), the classifier-
+// free-guidance form e_u + g (e_c - e_u) (ddim.py:260, plms.py:199).  Serves PLMS's Adams-Bashforth combinations
+// of the last noise predictions (plms.py:236-249).
+__global__ void lincomb_kernel(float* __restrict__ out, long n, const float* __restrict__ x0, float w0,
+                               const float* __restrict__ x1, float w1, const float* __restrict__ x2, float w2,
+                               const float* __restrict__ x3, float w3, int mode) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v;
+    if (mode == 1) {
+      const float a = x1[i];
+      v = a + w0 * (x0[i] - a);
+    } else {
+      v = w0 * x0[i];
+      if (x1) v += w1 * x1[i];
+      if (x2) v += w2 * x2[i];
+      if (x3) v += w3 * x3[i];
+    }
+    out[i] = v;
+  }
+}
+
 // row softmax in place over fp32-accumulated T rows: x[row][0..n) (VAE AttnBlock)
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(T* __restrict__ x, int ld, int ncols, long rows) {
@@ -251,6 +272,12 @@ int af_launch_ddim_step(const float* x, const float* eps_c, const float* eps_u, 
                         float temperature, float* x_prev, float* pred_x0, hipStream_t s) {
   hipLaunchKernelGGL(ddim_step_kernel, EW_GRID(n), dim3(256), 0, s, x, eps_c, eps_u, noise, n, guidance, a_t, a_prev,
                      sqrt_one_minus_at, sigma_t, temperature, x_prev, pred_x0);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int af_launch_lincomb(float* out, long n, const float* x0, float w0, const float* x1, float w1, const float* x2, float w2,
+                      const float* x3, float w3, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(lincomb_kernel, EW_GRID(n), dim3(256), 0, s, out, n, x0, w0, x1, w1, x2, w2, x3, w3, mode);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

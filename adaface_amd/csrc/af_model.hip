@@ -1210,6 +1210,13 @@ int af_ddim_step(const float* x_dev, const float* eps_cond_dev, const float* eps
                              reinterpret_cast<hipStream_t>(stream));
 }
 
+int af_lincomb(float* out_dev, int64_t n, const float* x0_dev, float w0, const float* x1_dev, float w1,
+               const float* x2_dev, float w2, const float* x3_dev, float w3, int mode, void* stream) {
+  if (!out_dev || !x0_dev || n <= 0 || (mode == 1 && !x1_dev)) { af_set_error_msg("af_lincomb: bad argument"); return AF_ERR_INVALID; }
+  return af_launch_lincomb(out_dev, (long)n, x0_dev, w0, x1_dev, w1, x2_dev, w2, x3_dev, w3, mode,
+                           reinterpret_cast<hipStream_t>(stream));
+}
+
 int af_vae_decode(af_handle* h, const float* z_dev, float scale_factor, float* img_dev, uint8_t* u8_dev, int B, int H,
                   int W, void* stream) {
   if (!h || !z_dev || (!img_dev && !u8_dev)) { af_set_error_msg("af_vae_decode: null argument"); return AF_ERR_INVALID; }

@@ -115,6 +115,21 @@ def ddim_step(x, e_cond, e_uncond, guidance, a_t, a_prev, sqrt_one_minus_at, sig
     return x_prev, pred_x0
 
 
+def lincomb(terms, cfg=False):
+    """sum_i w_i * x_i over up to four (tensor, weight) pairs; cfg=True: terms = [(e_cond, g), (e_uncond, _)] ->
+    e_uncond + g * (e_cond - e_uncond)."""
+    lib = _lib.load()
+    xs = [_dev_f32(t) for t, _ in terms]
+    ws = [float(w) for _, w in terms]
+    while len(xs) < 4:
+        xs.append(None)
+        ws.append(0.0)
+    out = torch.empty_like(xs[0])
+    check(lib.af_lincomb(ptr(out), out.numel(), ptr(xs[0]), ws[0], ptr(xs[1]), ws[1], ptr(xs[2]), ws[2], ptr(xs[3]), ws[3],
+                         1 if cfg else 0, stream_ptr()), "af_lincomb")
+    return out
+
+
 def to_uint8(img):
     """clamp((img+1)/2,0,1)*255 -> uint8 HWC (stable_txt2img.py:715,764-765)."""
     lib = _lib.load()

@@ -86,6 +86,11 @@ int af_ddim_step(const float* x_dev, const float* eps_cond_dev, const float* eps
                  int64_t n, float guidance, float a_t, float a_prev, float sqrt_one_minus_at, float sigma_t,
                  float temperature, float* x_prev_dev, float* pred_x0_dev, void* stream);
 
+/* out = w0 x0 + w1 x1 + w2 x2 + w3 x3 (NULL inputs skipped), fp32, n elements; mode 1: out = x1 + w0 (x0 - x1) = the CFG
+ * combine.  PLMS's Adams-Bashforth mixes of noise predictions (ldm/models/diffusion/plms.py:199,236-249). */
+int af_lincomb(float* out_dev, int64_t n, const float* x0_dev, float w0, const float* x1_dev, float w1,
+               const float* x2_dev, float w2, const float* x3_dev, float w3, int mode, void* stream);
+
 /* decode_first_stage + AutoencoderKL.decode (ddpm.py:1251-1308, autoencoder.py:330-333):
  * z_dev [B,zc,H,W] fp32 -> img_dev [B,out_ch,8H,8W] fp32 NCHW (may be NULL) and/or
  * u8_dev [B,8H,8W,3] uint8 HWC = clamp((x+1)/2,0,1)*255 truncated (stable_txt2img.py:715,764-765). */

@@ -468,12 +468,13 @@ def ddim_sample(apply_model: Callable[[Tensor, Tensor, Tensor], Tensor], schedul
     ts = make_ddim_timesteps(S, schedule["alphas_cumprod"].shape[0])
     sigmas, alphas, alphas_prev = make_ddim_sampling_parameters(schedule["alphas_cumprod"], ts, eta)
     sqrt_one_minus = np.sqrt(1.0 - alphas)
-    gs = guidance_schedule(guidance_scale, S)
+    n = len(ts)  # NOT S: make_ddim_timesteps yields ceil(1000 / (1000 // S)) steps (7 for S=6); ddim.py:160,181
+    gs = guidance_schedule(guidance_scale, n)
     b = x_T.shape[0]
     img = x_T
     traj = []
     for i, step in enumerate(np.flip(ts)):
-        index = S - i - 1
+        index = n - i - 1
         t = torch.full((b,), int(step), dtype=torch.long)
         e_c, e_u = apply_model(torch.cat([img] * 2), torch.cat([t] * 2), torch.cat([cond, uncond])).chunk(2)
         e_t = e_u + gs[i] * (e_c - e_u)
@@ -487,3 +488,47 @@ def ddim_sample(apply_model: Callable[[Tensor, Tensor, Tensor], Tensor], schedul
         if return_trajectory:
             traj.append(img.clone())
     return (img, traj) if return_trajectory else img
+
+
+def plms_sample(apply_model: Callable[[Tensor, Tensor, Tensor], Tensor], schedule: dict, S: int, x_T: Tensor,
+                cond: Tensor, uncond: Tensor, guidance_scale: float = 3.0):
+    """PLMSSampler.sample/plms_sampling/p_sample_plms (ldm/models/diffusion/plms.py:58-253), eta = 0:
+    CFG batch is cat[UNCOND, COND] (plms.py:193-199), scalar guidance, pseudo improved Euler first step then
+    Adams-Bashforth orders 2-4 over the last noise predictions (plms.py:230-249)."""
+    ts = make_ddim_timesteps(S, schedule["alphas_cumprod"].shape[0])
+    sigmas, alphas, alphas_prev = make_ddim_sampling_parameters(schedule["alphas_cumprod"], ts, 0.0)
+    sqrt_one_minus = np.sqrt(1.0 - alphas)
+    time_range = np.flip(ts)
+    b = x_T.shape[0]
+    img = x_T
+    old_eps: List[Tensor] = []
+
+    def model_out(x, t):
+        e_u, e_c = apply_model(torch.cat([x] * 2), torch.cat([t] * 2), torch.cat([uncond, cond])).chunk(2)
+        return e_u + guidance_scale * (e_c - e_u)
+
+    def step(x, e, index):
+        a_t = torch.full((b, 1, 1, 1), alphas[index])
+        a_prev = torch.full((b, 1, 1, 1), alphas_prev[index])
+        s1m = torch.full((b, 1, 1, 1), sqrt_one_minus[index])
+        pred_x0 = (x - s1m * e) / a_t.sqrt()
+        return a_prev.sqrt() * pred_x0 + (1.0 - a_prev).sqrt() * e
+
+    for i, stp in enumerate(time_range):
+        index = len(ts) - i - 1  # total_steps = timesteps.shape[0] (plms.py:139,146), 7 for S=6
+        t = torch.full((b,), int(stp), dtype=torch.long)
+        t_next = torch.full((b,), int(time_range[min(i + 1, len(time_range) - 1)]), dtype=torch.long)
+        e_t = model_out(img, t)
+        if len(old_eps) == 0:
+            e_prime = (e_t + model_out(step(img, e_t, index), t_next)) / 2
+        elif len(old_eps) == 1:
+            e_prime = (3 * e_t - old_eps[-1]) / 2
+        elif len(old_eps) == 2:
+            e_prime = (23 * e_t - 16 * old_eps[-1] + 5 * old_eps[-2]) / 12
+        else:
+            e_prime = (55 * e_t - 59 * old_eps[-1] + 37 * old_eps[-2] - 9 * old_eps[-3]) / 24
+        img = step(img, e_prime, index)
+        old_eps.append(e_t)
+        if len(old_eps) >= 4:
+            old_eps.pop(0)
+    return img

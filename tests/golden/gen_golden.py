@@ -24,7 +24,6 @@ import numpy as np
 import torch
 
 ROOT = Path(__file__).resolve().parents[2]
-sys.path.insert(0, str(ROOT))
 REF = "/root/reference"
 OUT = Path(__file__).resolve().parent
 
@@ -54,7 +53,16 @@ def main():
     sys.path.insert(0, REF)
     torch.set_grad_enabled(False)
     torch.manual_seed(0)
-    from oracle import ldm_oracle as O
+    # The repo root holds a drop-in `ldm` package of its own; it must NOT be importable here, so the oracle (used only
+    # for its seeded synthetic weights and config tuples) is loaded by file path and ROOT stays off sys.path.
+    import importlib.util
+    sys.path[:] = [p for p in sys.path if p and Path(p).resolve() != ROOT]
+    spec = importlib.util.spec_from_file_location("ldm_oracle", ROOT / "oracle" / "ldm_oracle.py")
+    O = importlib.util.module_from_spec(spec)
+    sys.modules["ldm_oracle"] = O
+    spec.loader.exec_module(O)
+    import ldm.modules.diffusionmodules.openaimodel as _om
+    assert _om.__file__.startswith(REF), f"ldm resolved to {_om.__file__}, not the reference"
     from ldm.modules.diffusionmodules.openaimodel import UNetModel
     from ldm.modules.diffusionmodules.model import Decoder
     from ldm.models.diffusion.ddim import DDIMSampler
@@ -155,6 +163,20 @@ def main():
                                 unconditional_conditioning=(uc, [""] * B, extra_info()), eta=0.0, x_T=x_T)
     golden["ddim_xT"], golden["ddim_c"], golden["ddim_uc"] = x_T.numpy(), c.numpy(), uc.numpy()
     golden["ddim_S5_samples"] = samples.numpy()
+
+    # ---- the same inputs through the reference PLMSSampler (S=6, scalar guidance 3.0; plms.py) ----
+    from ldm.models.diffusion.plms import PLMSSampler
+    PLMSSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    psampler = PLMSSampler(model)
+    psamples, _ = psampler.sample(S=6, conditioning=(c, ["p"] * B, extra_info()), batch_size=B, shape=[4, H, H],
+                                  verbose=False, unconditional_guidance_scale=3.0,
+                                  unconditional_conditioning=(uc, [""] * B, extra_info()), eta=0.0, x_T=x_T)
+    golden["plms_S6_samples"] = psamples.numpy()
+    # S=6 does not divide 1000: make_ddim_timesteps yields 7 steps; pins index/annealing arithmetic on len(timesteps)
+    s6, _ = sampler.sample(S=6, conditioning=(c, ["p"] * B, extra_info()), batch_size=B, shape=[4, H, H],
+                           verbose=False, guidance_scale=[6.0, 2.0],
+                           unconditional_conditioning=(uc, [""] * B, extra_info()), eta=0.0, x_T=x_T)
+    golden["ddim_S6_samples"] = s6.numpy()
 
     # ---- tiny VAE decoder ----
     vcfg = O.TINY_VAE

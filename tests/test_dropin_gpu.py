@@ -64,6 +64,31 @@ def test_ddim_sampler_matches_reference_sampler(gpu, report, tiny_model):
     s2, _ = sampler.sample(S=5, conditioning=c, batch_size=1, shape=[4, 16, 16], verbose=False, guidance_scale=[3.0, 3.0],
                            unconditional_conditioning=uc, eta=0.0, x_T=torch.tensor(g["ddim_xT"], device=gpu))
     assert torch.equal(s1, s2)
+    # S=6 -> 7 real steps (1000 // 6 = 166); annealing runs over len(timesteps)
+    s6, _ = sampler.sample(S=6, conditioning=c, batch_size=1, shape=[4, 16, 16], verbose=False, guidance_scale=[6.0, 2.0],
+                           unconditional_conditioning=uc, eta=0.0, x_T=torch.tensor(g["ddim_xT"], device=gpu))
+    ref = g["ddim_S6_samples"]
+    err = np.abs(s6.cpu().numpy() - ref).max() / np.abs(ref).max()
+    report("dropin DDIMSampler S=6 (7 steps) vs reference sampler [f32]", err, float(np.abs(ref).max()), 1e-3)
+    assert err < 1e-3
+
+
+def test_plms_sampler_matches_reference_sampler(gpu, report, tiny_model):
+    """PLMSSampler (the reference's --plms path): uncond-first CFG batch, Adams-Bashforth multistep."""
+    from ldm.models.diffusion.plms import PLMSSampler
+    g = dict(np.load(GOLD / "golden_tiny.npz"))
+    c = tiny_model.get_learned_conditioning(torch.tensor(g["ddim_c"], device=gpu))
+    uc = tiny_model.get_learned_conditioning(torch.tensor(g["ddim_uc"], device=gpu))
+    sampler = PLMSSampler(tiny_model)
+    samples, _ = sampler.sample(S=6, conditioning=c, batch_size=1, shape=[4, 16, 16], verbose=False,
+                                unconditional_guidance_scale=3.0, unconditional_conditioning=uc, eta=0.0,
+                                x_T=torch.tensor(g["ddim_xT"], device=gpu))
+    ref = g["plms_S6_samples"]
+    err = np.abs(samples.cpu().numpy() - ref).max() / np.abs(ref).max()
+    report("dropin PLMSSampler S=6 vs reference sampler [f32]", err, float(np.abs(ref).max()), 1e-3)
+    assert err < 1e-3
+    with pytest.raises(ValueError):
+        sampler.sample(S=6, conditioning=c, batch_size=1, shape=[4, 16, 16], verbose=False, eta=0.5)
 
 
 def test_decode_first_stage_and_uint8(gpu, report, tiny_model):

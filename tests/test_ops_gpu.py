@@ -197,6 +197,20 @@ def test_ddim_step(gpu, report):
     _cmp(report, "ddim pred_x0", p0, pred, "f32", tol_scale=0.05)
 
 
+def test_lincomb(gpu, report):
+    """The PLMS multistep combinations (plms.py:236-249) and the uncond-first CFG combine (plms.py:199)."""
+    from adaface_amd import ops
+    g = torch.Generator().manual_seed(10)
+    e = [torch.randn(2, 4, 33, 31, generator=g) for _ in range(4)]  # odd size: exercises the vector tail
+    d = [t.to(gpu) for t in e]
+    ref4 = (55 * e[0] - 59 * e[1] + 37 * e[2] - 9 * e[3]) / 24
+    _cmp(report, "lincomb AB4", ops.lincomb([(d[0], 55 / 24), (d[1], -59 / 24), (d[2], 37 / 24), (d[3], -9 / 24)]), ref4,
+         "f32", tol_scale=0.05)
+    _cmp(report, "lincomb AB2", ops.lincomb([(d[0], 1.5), (d[1], -0.5)]), (3 * e[0] - e[1]) / 2, "f32", tol_scale=0.05)
+    _cmp(report, "lincomb cfg", ops.lincomb([(d[0], 3.0), (d[1], 0.0)], cfg=True), e[1] + 3.0 * (e[0] - e[1]), "f32",
+         tol_scale=0.05)
+
+
 def test_to_uint8(gpu):
     from adaface_amd import ops
     g = torch.Generator().manual_seed(3)

@@ -84,6 +84,21 @@ def test_tiny_ddim_matches_reference_sampler(tiny):
     assert err < 1e-5 * np.abs(ref).max(), err
 
 
+def test_tiny_plms_matches_reference_sampler(tiny):
+    cfg = O.TINY_UNET
+    sd = O.synth_state_dict(O.unet_param_shapes(cfg), seed=11)
+    apply = lambda x, t, c: O.unet_forward(sd, cfg, x, t, c)
+    out = O.plms_sample(apply, O.register_schedule(), 6, torch.tensor(tiny["ddim_xT"]), torch.tensor(tiny["ddim_c"]),
+                        torch.tensor(tiny["ddim_uc"]), guidance_scale=3.0)
+    ref = tiny["plms_S6_samples"]
+    assert np.abs(out.numpy() - ref).max() < 1e-5 * np.abs(ref).max()
+    # S=6 -> 7 actual steps (1000 // 6 = 166): annealing and table indices run over len(timesteps), not S
+    out = O.ddim_sample(apply, O.register_schedule(), 6, torch.tensor(tiny["ddim_xT"]), torch.tensor(tiny["ddim_c"]),
+                        torch.tensor(tiny["ddim_uc"]), guidance_scale=(6.0, 2.0))
+    ref = tiny["ddim_S6_samples"]
+    assert np.abs(out.numpy() - ref).max() < 1e-5 * np.abs(ref).max()
+
+
 def test_tiny_vae_matches_reference(tiny):
     sd = O.synth_state_dict(O.vae_param_shapes(O.TINY_VAE), seed=12)
     img = O.vae_decode(sd, O.TINY_VAE, torch.tensor(tiny["vae_z"]))
