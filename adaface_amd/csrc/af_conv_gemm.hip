@@ -32,11 +32,12 @@
 //   * split-K (deep-K, small-M layers at 8x8 / 16x16): K slices write fp32 slabs,
 //     a second kernel reduces them and applies the epilogue.
 //   * fused epilogues: alpha, bias, per-sample time-embedding bias, residual add,
-//     GEGLU (value*gelu(gate) with value/gate rows interleaved in 32-row groups).
+//     GEGLU (value*gelu(gate) with value/gate rows interleaved in 16-row groups).
 #include "af_kernels.h"
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 template <int BM, int BN> struct TileCfg {
   static constexpr int XR = BM / 32, WR = BN / 32;
@@ -336,25 +337,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   if (geglu) {
     if constexpr (NI == 2) {
       BNo = BN / 2;
-      // packed weight rows [g*64, g*64+32) are "value", [g*64+32, g*64+64) "gate"; a wave's 64 columns = one group
+      // packed weight rows [32k, 32k+16) are "value", [32k+16, 32k+32) "gate": within a 32-column MFMA block the
+      // value sits in accumulator registers 0-7 (columns 8q+4h+e, q < 2) and its gate in registers 8-15 of the SAME lane
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int row = wm * C::WM + mi * 32 + l31;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int j = 8 * q + 4 * h;
-          const int nv = n0 + wn * 64 + j;  // packed row index of the value (bias is packed the same way)
-          float4 o;
-          float* op = reinterpret_cast<float*>(&o);
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float val = acc[0][mi][4 * q + e] * p.alpha;
-            float gat = acc[1][mi][4 * q + e] * p.alpha;
-            if (p.bias) { val += p.bias[nv + e]; gat += p.bias[nv + 32 + e]; }
-            op[e] = val * gelu_erf_f(gat);
+          for (int q = 0; q < 2; ++q) {
+            const int j = 8 * q + 4 * h;
+            const int nv = n0 + wn * 64 + ni * 32 + j;  // packed row index of the value (bias is packed the same way)
+            float4 o;
+            float* op = reinterpret_cast<float*>(&o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float val = acc[ni][mi][4 * q + e] * p.alpha;
+              float gat = acc[ni][mi][4 * (q + 2) + e] * p.alpha;
+              if (p.bias) { val += p.bias[nv + e]; gat += p.bias[nv + 16 + e]; }
+              op[e] = val * gelu_erf_f(gat);
+            }
+            *reinterpret_cast<float4*>(et + row * C::EPI_LD + wn * 32 + ni * 16 + j) = o;
           }
-          *reinterpret_cast<float4*>(et + row * C::EPI_LD + wn * 32 + j) = o;
-        }
       }
     }
   } else {
@@ -417,240 +421,308 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 }
 
 // ---------------------------------------------------------------------------
-// Wide tile: 256 x BN (BN = 128 or 256), 8 waves as 4(M) x 2(N), LDS-DMA staging only.
+// "Ping-pong" tile: 256 x BN x 64 (BN = 160 or 128), 512 threads, bf16, LDS-DMA ring of three K tiles.
 //
-// The 128x128 / 4-wave structure tops out near 900 TFLOP/s (one barrier per 16 MFMAs, 64 B of L2->LDS traffic per
-// MFMA-clock at peak).  Doubling both tile edges halves the staged bytes per FLOP and puts 16-32 MFMAs per wave
-// between barriers; with LDS-DMA there is no VGPR staging, so the 128 accumulator registers of a 64x128 wave tile
-// fit.  Used for the big-M, big-N layers (GEGLU projections, fused QKV, up-sample convs, VAE).  Same gather, swizzle,
-// fused epilogues and XCD-aware grid as conv_gemm_kernel; the epilogue goes through LDS in 64/128-row slabs.
+// The 128x128 / 4-wave structure above tops out near 900 TFLOP/s: every wave alternates LDS reads, MFMAs and a
+// barrier, so the matrix pipe idles while fragments are fetched.  Here waves 0-3 (group 0, one per SIMD) and waves
+// 4-7 (group 1, their SIMD partners) run the SAME program one barrier apart (lab: scripts/lab/gemm_pp_lab.hip):
+//
+//     interval 2t   : group 0  D(t)  issue LDS-DMA              | group 1  C(t-1) MFMAs
+//     interval 2t+1 : group 0  C(t)  MFMAs + fragment reads     | group 1  D(t)
+//
+//   * D(t): group 0 issues its pieces of K tile t+1, group 1 its pieces of tile t+2 (a piece = 8 rows x 128 B = one
+//     buffer_load_dwordx4 ... lds; 7 / 6 pieces per wave at BN = 160).  Nothing else: a DMA costs the issuing wave
+//     60-75 cycles, so the fragment reads do not live here.
+//   * C(t): the MFMAs run half a tile behind the reads: [read unit 2t | MFMA unit 2t-1] [read unit 2t+1 | MFMA
+//     unit 2t] (unit = 32 of the tile's 64 K values), one ds_read_b128 issued behind each of the first nine MFMAs of
+//     a half, so fragment registers stay at one tile (72 VGPRs) and the reads' latency is covered by MFMAs.
+//   * counted s_waitcnt vmcnt(N) (never 0 inside the loop) + raw s_barrier: a tile is waited for by the waves that
+//     issued it one barrier before its first reader, and a slot is refilled only after the barrier that follows its
+//     last reader's lgkmcnt(0).  Fragment reads are inline asm: hipcc puts s_waitcnt vmcnt(0) in front of any LDS
+//     read it can see after an LDS-DMA, which would drain the ring every tile.
+//   * each wave owns 64 rows x BN/2 columns as 4 x (BN/32) MFMA 16x16x32 blocks; the weight tile is the MFMA A
+//     operand, so a lane holds 4 consecutive output channels of one output pixel.
+//   * swizzle on the DMA SOURCE address (LDS-DMA writes lane-linearly): slot c' of row r holds chunk c' ^ (r & 7),
+//     conflict-free for the 16-lane groups of ds_read_b128 on 16-row fragments.
+//   * epilogue through LDS in two 128-row passes (fp32), then the same 16-byte row stores as conv_gemm_kernel.
+// Measured on plain GEMMs (lab): 1.15-1.27 PFLOP/s where the 128x128 kernel gives 0.6-0.9.
 // ---------------------------------------------------------------------------
-template <int BN> struct WideCfg {
-  static constexpr int BM = 256, NT = 512;
-  static constexpr int XR = BM / 64, WR = BN / 64;       // DMA instructions per thread per K tile
-  static constexpr int WM = 64, WN = BN / 2;
-  static constexpr int MI = 2, NI = WN / 32;
-  static constexpr int TILE_BYTES = (BM + BN) * 128;
+template <int BN> struct PpCfg {
+  static constexpr int BM = 256, BK = 64;
+  static constexpr int HN = BN / 2;                 // columns per wave group
+  static constexpr int NI = HN / 16, MI = 4;        // 16x16 blocks per wave
+  static constexpr int XBYTES = BM * 128, WBYTES = BN * 128, SLOT = XBYTES + WBYTES;
+  static constexpr int XP = BM / 8, WP = BN / 8;    // 1-KiB pieces per K tile
+  static constexpr int XP0 = ((XP + WP + 7) / 8) * 4;  // activation pieces staged by group 0
+  static constexpr int NP0 = XP0 / 4;               // pieces per wave, group 0 (all activation)
+  static constexpr int NX1 = (XP - XP0) / 4;        // activation pieces per wave, group 1
+  static constexpr int NW1 = WP / 4;                // weight pieces per wave, group 1
+  static constexpr int NP1 = NX1 + NW1;
+  static constexpr int NPMAX = NP0 > NP1 ? NP0 : NP1;
   static constexpr int EPI_LD = BN + 4;
-  static constexpr int EROWS = BN == 256 ? 64 : 128;     // rows per epilogue slab
-  static constexpr int EPI_BYTES = EROWS * EPI_LD * 4;
-  static constexpr int LDS_BYTES = (2 * TILE_BYTES > EPI_BYTES) ? 2 * TILE_BYTES : EPI_BYTES;
+  static constexpr int EPI_BYTES = 128 * EPI_LD * 4;
+  static constexpr int LDS_BYTES = 3 * SLOT;
+  static_assert(XP0 % 4 == 0 && (XP - XP0) % 4 == 0 && WP % 4 == 0 && HN % 16 == 0, "piece split");
+  static_assert(EPI_BYTES <= LDS_BYTES && NP0 >= NX1, "epilogue tile / gather state");
 };
 
-template <typename T, int BN>
-__global__ __launch_bounds__(512) void gemm_wide_kernel(const ConvGemmParams p) {
-  using C = WideCfg<BN>;
-  constexpr int BM = C::BM, BK = 128 / sizeof(T);
-  constexpr int XR = C::XR, WR = C::WR, MI = C::MI, NI = C::NI;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+typedef __attribute__((ext_vector_type(4))) unsigned pp_u32x4;
+template <int I, int N, typename F> __device__ __forceinline__ void pp_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    pp_static_for<I + 1, N>(f);
+  }
+}
+template <int OFF> __device__ __forceinline__ pp_u32x4 pp_lds_read128(unsigned addr) {
+  pp_u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void pp_wait_lgkm0() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);   // hipcc hoists register-only MFMAs over an asm wait without this
+}
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int h = lane >> 5, l31 = lane & 31;
-  const int wm = wave & 3, wn = wave >> 2;
+template <int BN, bool GATHER>
+__global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams p) {
+  using C = PpCfg<BN>;
+  typedef bf16 T;
+  constexpr int NI = C::NI, MI = C::MI, SLOT = C::SLOT, XBYTES = C::XBYTES;
+  constexpr int NP0 = C::NP0, NX1 = C::NX1, NW1 = C::NW1, NP1 = C::NP1, NPMAX = C::NPMAX, XP0 = C::XP0;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
 
-  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wid >> 2, wq = wid & 3;
+  const int ntm = (p.M + 255) / 256, ntn = p.N / BN;
   int tm, tn;
   tile_coords(blockIdx.x, gridDim.x, ntm, ntn, p.group_m, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const long zb = blockIdx.z;
+  const int m0 = tm * 256, n0 = tn * BN;
+  const int zk = blockIdx.z;
 
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(reinterpret_cast<const T*>(p.src) + zb * p.bs_src), 0, (int)0xFFFFFFF0u, 0x00020000);
+      const_cast<T*>(reinterpret_cast<const T*>(p.src)), 0, (int)0xFFFFFFF0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(reinterpret_cast<const T*>(p.W) + zb * p.bs_w), 0, (int)0xFFFFFFF0u, 0x00020000);
+      const_cast<T*>(reinterpret_cast<const T*>(p.W)), 0, (int)0xFFFFFFF0u, 0x00020000);
 
-  const int chunk = tid & 7, r0 = tid >> 3;               // r0 in [0,64); rows r0 + 64*i
-  const int schunk = chunk ^ ((r0 >> 1) & 7);             // swizzle on the SOURCE side (LDS-DMA writes lane-linearly)
+  // K range of this block (split-K slices)
+  const int KT_all = p.K / 64;
+  const int kt_per = (KT_all + p.splitk - 1) / p.splitk;
+  const int kt_begin = zk * kt_per;
+  const int KT = min(KT_all, kt_begin + kt_per) - kt_begin;
+
+  // ---- staging state.  Piece q of this wave: group 0: activation piece wq + 4q (q < NP0); group 1: activation
+  // piece XP0 + wq + 4q (q < NX1), then weight piece wq + 4(q - NX1).  Lane: row lane>>3 of the piece, LDS slot
+  // lane&7, which receives data chunk (lane&7) ^ (row&7).
+  const int srow = lane >> 3;
+  const unsigned lchunk = (unsigned)((lane & 7) ^ srow) * 16u;
   const int HoWo = p.Ho * p.Wo;
-  const unsigned ldcb = (unsigned)p.ldc * (unsigned)sizeof(T);
-
-  int x_iy0[XR], x_ix0[XR];
-  unsigned x_off[XR];
-  bool x_ok[XR];
-#pragma unroll
-  for (int i = 0; i < XR; ++i) {
-    int m = m0 + r0 + 64 * i;
-    bool ok = m < p.M;
-    int mm = ok ? m : 0;
-    int b = mm / HoWo;
-    int rem = mm - b * HoWo;
-    int oy = rem / p.Wo;
-    int ox = rem - oy * p.Wo;
-    x_iy0[i] = oy * p.stride - p.pad;
-    x_ix0[i] = ox * p.stride - p.pad;
-    x_off[i] = (unsigned)((long)b * p.src_batch_stride * (long)sizeof(T)) + (unsigned)(schunk * 16);
-    x_ok[i] = ok;
-  }
-  unsigned w_off[WR];
-#pragma unroll
-  for (int i = 0; i < WR; ++i) {
-    int n = n0 + r0 + 64 * i;
-    w_off[i] = n < p.Wrows ? (unsigned)(((long)n * p.ldw) * (long)sizeof(T)) + (unsigned)(schunk * 16) : 0xFFFFFFFFu;
-  }
-
-  const int KT = p.K / BK;
-  int ky = 0, kx = 0, c0 = 0;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  auto gdma = [&](int buf, int k0) {
-    char* xs = smem + buf * C::TILE_BYTES + wv * 1024;
-    char* ws = xs + BM * 128;
-    const unsigned c0b = (unsigned)c0 * (unsigned)sizeof(T);
-#pragma unroll
-    for (int i = 0; i < XR; ++i) {
-      const int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
-      const bool ok = x_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      const unsigned pix = (unsigned)((iy >> p.up) * p.Ws + (ix >> p.up));
-      const unsigned vo = ok ? x_off[i] + pix * ldcb : 0xFFFFFFFFu;
-      lds_dma16(rs_x, xs + i * 8192, vo, c0b);
+  const unsigned ldcb = (unsigned)p.ldc * 2u;
+  unsigned x_off[NP0];
+  int x_yx[GATHER ? NP0 : 1];   // (iy0 << 16) | (ix0 & 0xffff): input coordinate of tap (0,0)
+  pp_static_for<0, NP0>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    const int piece = g == 0 ? wq + 4 * q : XP0 + wq + 4 * q;
+    const int m = m0 + piece * 8 + srow;
+    const bool ok = m < p.M && (g == 0 || q < NX1);
+    const int mm = ok ? m : 0;
+    const int b = mm / HoWo;
+    const int rem = mm - b * HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    unsigned off = (unsigned)((long)b * p.src_batch_stride * 2) + lchunk;
+    if constexpr (GATHER) {
+      x_yx[q] = ok ? (((oy * p.stride - p.pad) << 16) | ((ox * p.stride - p.pad) & 0xffff)) : (int)0xC0000000;
+    } else {
+      off += (unsigned)(((oy * p.stride) >> p.up) * p.Ws + ((ox * p.stride) >> p.up)) * ldcb;
+      if (!ok) off = 0xFFFFFFFFu;
     }
-    const unsigned k0b = (unsigned)k0 * (unsigned)sizeof(T);
+    x_off[q] = off;
+  });
+  unsigned w_off[NW1];
 #pragma unroll
-    for (int i = 0; i < WR; ++i) lds_dma16(rs_w, ws + i * 8192, w_off[i], k0b);
-    c0 += BK;
+  for (int q = 0; q < NW1; ++q) {
+    const int n = n0 + (wq + 4 * q) * 8 + srow;
+    w_off[q] = n < p.Wrows ? (unsigned)((long)n * p.ldw * 2) + lchunk : 0xFFFFFFFFu;
+  }
+  int ky, kx, c0, ktile = kt_begin;   // filter tap / channel offset / K tile of the NEXT tile this wave stages
+  {
+    const int k0 = kt_begin * 64;
+    const int tap = k0 / p.Cin;
+    c0 = k0 - tap * p.Cin;
+    ky = tap / p.ks;
+    kx = tap - ky * p.ks;
+  }
+  auto x_addr = [&](auto qc) -> unsigned {
+    constexpr int q = decltype(qc)::value;
+    if constexpr (GATHER) {
+      const int iy = (x_yx[q] >> 16) + ky, ix = ((x_yx[q] << 16) >> 16) + kx;
+      const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      const unsigned pix = (unsigned)((iy >> p.up) * p.Ws + (ix >> p.up));
+      return ok ? x_off[q] + pix * ldcb : 0xFFFFFFFFu;
+    } else {
+      return x_off[q];
+    }
+  };
+  auto stage = [&](int slot_off) {
+    const unsigned c0b = (unsigned)c0 * 2u, k0b = (unsigned)ktile * 128u;
+    char* base = smem + slot_off;
+    pp_static_for<0, NPMAX>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      if (g == 0) {
+        if constexpr (q < NP0) lds_dma16(rs_x, base + (wq + 4 * q) * 1024, x_addr(qc), c0b);
+      } else {
+        if constexpr (q < NX1) lds_dma16(rs_x, base + (XP0 + wq + 4 * q) * 1024, x_addr(qc), c0b);
+        else if constexpr (q < NP1) lds_dma16(rs_w, base + XBYTES + (wq + 4 * (q - NX1)) * 1024, w_off[q - NX1], k0b);
+      }
+    });
+    ++ktile;
+    c0 += 64;
     if (c0 >= p.Cin) {
       c0 = 0;
       if (++kx >= p.ks) { kx = 0; ++ky; }
     }
   };
+  auto wait_keep1 = [&]() { if (g == 0) pp_wait_vm<NP0>(); else pp_wait_vm<NP1>(); };
 
-  f32x16 acc[NI][MI];
-#pragma unroll
-  for (int a = 0; a < NI; ++a)
-#pragma unroll
-    for (int b = 0; b < MI; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  // ---- fragments: row (lane & 15) of a 16-row block, chunk ((lane >> 4) + 4 u) ^ (row & 7), u = K half ----
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) char*)smem);
+  const unsigned fch0 = (unsigned)((lane >> 4) ^ (lane & 7)) * 16u;
+  const unsigned fch1 = (unsigned)(((lane >> 4) + 4) ^ (lane & 7)) * 16u;
+  const unsigned x_base = (unsigned)((wq * 64 + (lane & 15)) * 128);
+  const unsigned w_base = (unsigned)(XBYTES + (g * C::HN + (lane & 15)) * 128);
 
-  auto compute = [&](int buf) {
-    const char* xs = smem + buf * C::TILE_BYTES;
-    const char* ws = xs + BM * 128;
-    // fragment double buffering only where the register budget allows (BN = 128); at BN = 256 the 128 accumulator
-    // registers leave room for one fragment set and the two waves per SIMD cover the LDS latency for each other
-    constexpr int NFB = (BN == 256) ? 1 : 2;
-    uint4 xf[NFB][MI], wf[NFB][NI];
+  f32x4 acc[NI][MI];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-      xf[0][mi] = *reinterpret_cast<const uint4*>(xs + lds_off(wm * 64 + mi * 32 + l31, h));
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-      wf[0][ni] = *reinterpret_cast<const uint4*>(ws + lds_off(wn * C::WN + ni * 32 + l31, h));
+    for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  pp_u32x4 xf[MI][2], wf[NI][2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (NFB == 2 && s < 3) {
+  for (int i = 0; i < NI; ++i) wf[i][1] = pp_u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          xf[(s + 1) % NFB][mi] =
-              *reinterpret_cast<const uint4*>(xs + lds_off(wm * 64 + mi * 32 + l31, 2 * (s + 1) + h));
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          wf[(s + 1) % NFB][ni] =
-              *reinterpret_cast<const uint4*>(ws + lds_off(wn * C::WN + ni * 32 + l31, 2 * (s + 1) + h));
-      }
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) Mma<T>::step(wf[s % NFB][ni], xf[s % NFB][mi], acc[ni][mi]);
-      if (NFB == 1 && s < 3) {
-        // keep hipcc from hoisting all 24 fragment reads of the K tile above the MFMAs (it then spills them)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          xf[0][mi] = *reinterpret_cast<const uint4*>(xs + lds_off(wm * 64 + mi * 32 + l31, 2 * (s + 1) + h));
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          wf[0][ni] = *reinterpret_cast<const uint4*>(ws + lds_off(wn * C::WN + ni * 32 + l31, 2 * (s + 1) + h));
-      }
-    }
+  for (int j = 0; j < MI; ++j) xf[j][1] = pp_u32x4{0u, 0u, 0u, 0u};
+
+  // one half of a compute segment: MFMAs of unit UM, the NI + MI fragment reads of unit UR one behind each of the
+  // first MFMAs (in-order issue: reads placed after the MFMAs would not overlap them)
+  auto half = [&](int slot_off, auto rc, auto mc) {
+    constexpr int ur = decltype(rc)::value, um = decltype(mc)::value;
+    const unsigned b = lds0 + (unsigned)slot_off + (ur ? fch1 : fch0);
+    pp_static_for<0, NI * MI>([&](auto nc) {
+      constexpr int n = decltype(nc)::value;
+      constexpr int i = n / MI, j = n % MI;
+      if constexpr (n < NI) wf[n][ur] = pp_lds_read128<n * 2048>(b + w_base);
+      else if constexpr (n < NI + MI) xf[n - NI][ur] = pp_lds_read128<(n - NI) * 2048>(b + x_base);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i][um]),
+                                                          __builtin_bit_cast(bf16x8, xf[j][um]), acc[i][j], 0, 0, 0);
+      if constexpr (n < NI + MI) __builtin_amdgcn_sched_barrier(0);
+    });
   };
+  std::integral_constant<int, 0> U0;
+  std::integral_constant<int, 1> U1;
 
-  if (KT > 0) gdma(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < KT) gdma(cur ^ 1, (kt + 1) * BK);
-    compute(cur);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  // ---- prologue: tile 0 (group 1 also tile 1) in flight; group 1's part of tile 0 landed ----
+  stage(0);
+  if (g == 1) {
+    if (KT > 1) { stage(SLOT); wait_keep1(); } else pp_wait_vm<0>();
   }
+  __builtin_amdgcn_s_barrier();
+  if (g == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one interval behind
+  int rd = 0, w0 = SLOT, w1 = 2 * SLOT;       // slots of tiles t, t+1, t+2
+  for (int t = 0; t < KT; ++t) {
+    // ---------------- D(t) ----------------
+    if (g == 0) {
+      if (t + 1 < KT) { stage(w0); wait_keep1(); } else pp_wait_vm<0>();   // own part of tile t landed
+    } else {
+      if (t + 2 < KT) stage(w1);
+    }
+    __builtin_amdgcn_s_barrier();
+    // ---------------- C(t) ----------------
+    __builtin_amdgcn_s_setprio(1);
+    half(rd, U0, U1);      // (t == 0: MFMAs on the zeroed fragments of "unit -1")
+    pp_wait_lgkm0();
+    half(rd, U1, U0);
+    pp_wait_lgkm0();       // every read of tile t is back: the barrier below releases its slot
+    __builtin_amdgcn_s_setprio(0);
+    if (g == 1) { if (t + 2 < KT) wait_keep1(); else pp_wait_vm<0>(); }    // own part of tile t+1 landed
+    __builtin_amdgcn_s_barrier();
+    const int tmp = rd; rd = w0; w0 = w1; w1 = tmp;
+  }
+  // trailing half tile (unit 2 KT - 1), registers only
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i][1]),
+                                                          __builtin_bit_cast(bf16x8, xf[j][1]), acc[i][j], 0, 0, 0);
+  if (g == 0) __builtin_amdgcn_s_barrier();
 
-  // ---- epilogue in slabs of EROWS rows through LDS ----
+  // ------------------------------- epilogue -------------------------------
+  // two passes of 128 rows: waves with (wq >> 1) == pass put their accumulators into an fp32 LDS tile, then all 512
+  // threads walk it in 8-column vectors (a wave covers whole contiguous rows)
   float* et = reinterpret_cast<float*>(smem);
   const bool geglu = p.epilogue == AF_EPI_GEGLU;
   const int BNo = geglu ? BN / 2 : BN;
-  const int tpr = BNo >> 3, rpp = 512 / tpr;
-  const int trow = tid / tpr, c8 = (tid - trow * tpr) * 8;
+  const int tpr = BNo >> 3;
   const int ncol0 = geglu ? (n0 >> 1) : n0;
   const int Nvalid = geglu ? (p.N >> 1) : p.N;
-  const int n = ncol0 + c8;
-  T* __restrict__ out = reinterpret_cast<T*>(p.out) + zb * p.bs_out;
-  const T* __restrict__ res = p.residual ? reinterpret_cast<const T*>(p.residual) + zb * p.bs_res : nullptr;
+  T* __restrict__ out = reinterpret_cast<T*>(p.out);
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
   const T* __restrict__ rowb = reinterpret_cast<const T*>(p.rowbias);
   const float* __restrict__ bias = geglu ? nullptr : p.bias;
-  constexpr int NSLAB = BM / C::EROWS, WPS = C::EROWS / 64;  // wave rows per slab
+  float* slab = p.splitk > 1 ? reinterpret_cast<float*>(p.ws) + (long)zk * p.M * p.N : nullptr;
 #pragma unroll 1
-  for (int slab = 0; slab < NSLAB; ++slab) {
-    if (wm / WPS == slab) {
-      const int rbase = (wm % WPS) * 64;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass) __syncthreads();
+    if ((wq >> 1) == pass) {
+      const int rbase = (wq & 1) * 64 + (lane & 15);
+      const int cl = 4 * (lane >> 4);
       if (geglu) {
+        if constexpr ((NI & 1) == 0) {
+          // packed weight rows [32k, 32k+16) are "value", [32k+16, 32k+32) "gate": blocks 2k / 2k+1 of this wave
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int row = rbase + mi * 32 + l31;
+          for (int j = 0; j < MI; ++j)
 #pragma unroll
-          for (int g = 0; g < NI / 2; ++g)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int j = 8 * q + 4 * h;
-              const int nv = n0 + wn * C::WN + g * 64 + j;  // packed row of the value; gate = +32
+            for (int k2 = 0; k2 < NI / 2; ++k2) {
+              const int nv = n0 + g * C::HN + k2 * 32 + cl;   // packed column of the value (bias is packed alike)
               float4 o;
               float* op = reinterpret_cast<float*>(&o);
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                float val = acc[2 * g][mi][4 * q + e];   // alpha is 1 for every GEGLU projection
-                float gat = acc[2 * g + 1][mi][4 * q + e];
-                if (p.bias) { val += p.bias[nv + e]; gat += p.bias[nv + 32 + e]; }
+                float val = acc[2 * k2][j][e] * p.alpha, gat = acc[2 * k2 + 1][j][e] * p.alpha;
+                if (p.bias) { val += p.bias[nv + e]; gat += p.bias[nv + 16 + e]; }
                 op[e] = val * gelu_erf_f(gat);
               }
-              *reinterpret_cast<float4*>(et + row * C::EPI_LD + wn * (C::WN / 2) + g * 32 + j) = o;
+              *reinterpret_cast<float4*>(et + (rbase + j * 16) * C::EPI_LD + g * (C::HN / 2) + k2 * 16 + cl) = o;
             }
         }
       } else {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int row = rbase + mi * 32 + l31;
+        for (int j = 0; j < MI; ++j)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              // raw accumulators; alpha is applied after the LDS transpose (multiplying here makes hipcc
-              // materialise all 128 scaled values at once and spill)
-              float4 o;
-              o.x = acc[ni][mi][4 * q + 0]; o.y = acc[ni][mi][4 * q + 1];
-              o.z = acc[ni][mi][4 * q + 2]; o.w = acc[ni][mi][4 * q + 3];
-              *reinterpret_cast<float4*>(et + row * C::EPI_LD + wn * C::WN + ni * 32 + 8 * q + 4 * h) = o;
-            }
-        }
+          for (int i = 0; i < NI; ++i) {
+            float4 o;
+            o.x = acc[i][j][0] * p.alpha; o.y = acc[i][j][1] * p.alpha;
+            o.z = acc[i][j][2] * p.alpha; o.w = acc[i][j][3] * p.alpha;
+            *reinterpret_cast<float4*>(et + (rbase + j * 16) * C::EPI_LD + g * C::HN + i * 16 + cl) = o;
+          }
       }
     }
     __syncthreads();
-    if (n < Nvalid) {
-      const int nvalid = min(8, Nvalid - n);
-      for (int row = trow; row < C::EROWS; row += rpp) {
-        const int m = m0 + slab * C::EROWS + row;
-        if (m >= p.M) break;
-        float v[8];
-        const float4 a = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8);
-        const float4 b4 = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8 + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
-        if (!geglu) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-        }
-        epi_store8<T>(p, v, m, rowb ? m / HoWo : 0, n, nvalid, out, res, rowb, bias);
+    for (int idx = tid; idx < 128 * tpr; idx += 512) {
+      const int row = idx / tpr, c8 = (idx - row * tpr) * 8;
+      const int m = m0 + pass * 128 + row, n = ncol0 + c8;
+      if (m >= p.M || n >= Nvalid) continue;
+      const float4 a = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8);
+      const float4 b4 = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8 + 4);
+      if (slab) {
+        *reinterpret_cast<float4*>(slab + (long)m * p.N + n) = a;
+        if (n + 4 < Nvalid) *reinterpret_cast<float4*>(slab + (long)m * p.N + n + 4) = b4;
+      } else {
+        float v[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
+        epi_store8<T>(p, v, m, rowb ? m / HoWo : 0, n, min(8, Nvalid - n), out, res, rowb, bias);
       }
     }
-    __syncthreads();
   }
 }
 
@@ -920,6 +992,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvGemmParams
 // ---------------------------------------------------------------------------
 // planning (tile shape + split-K) and launch
 // ---------------------------------------------------------------------------
+AfGemmPlan g_af_last_plan = {0, 1, 0, 0, 1};
+
 static int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   return s ? atoi(s) : dflt;
@@ -977,28 +1051,45 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
       if (!n128 && (p.N % 64) != 0) pl.tile = 2;
     }
   }
-  // wide 8-wave tiles (experimental, off by default: with the simple 2-barrier pipeline they measured 5-15 % slower
-  // than 128x128 on every SD-1.5 shape and 2.6x slower on GEGLU, whose epilogue serialises over the row slabs)
-  if (!pl.halo_tw && pl.splitk == 1 && env_int("AF_GEMM_WIDE", 0)) {
-    const long tm256 = (p.M + 255) / 256;
-    const long nb256 = tm256 * ((p.N + 255) / 256) * batch, nb128 = tm256 * ((p.N + 127) / 128) * batch;
-    const double waste256 = (double)((p.N + 255) / 256 * 256) / p.N, waste128 = (double)((p.N + 127) / 128 * 128) / p.N;
-    if (p.N >= 512 && nb256 >= 512 && waste256 <= 1.07) pl.tile = 5;
-    else if (p.N >= 256 && nb128 >= 512 && waste128 <= 1.07) pl.tile = 4;
+  // ping-pong 256 x {160,128} tiles (bf16): preferred wherever the grid fills the chip.  tile 5 = BN 160 (divides
+  // every SD-1.5 channel count), tile 4 = BN 128 (GEGLU needs an even number of 16-column blocks per wave; VAE widths)
+  if (elem_size == 2 && batch == 1 && p.K % 64 == 0 && p.Cin % 64 == 0 && env_int("AF_GEMM_PP", 1)) {
+    int cand = -1;
+    if (!geglu && p.N % 160 == 0) cand = 5;
+    else if (p.N % 128 == 0) cand = 4;
+    if (cand >= 0) {
+      const int tbn = cand == 5 ? 160 : 128;
+      const long nb = (long)((p.M + 255) / 256) * (p.N / tbn);
+      int s = 1;
+      if (!geglu && nb < 208) {
+        // slice K until the 256 CUs are covered; every slice keeps >= 8 K tiles
+        s = (int)((256 + nb / 2) / nb);
+        if (s > KT / 8) s = KT / 8;
+        if (s > 16) s = 16;
+        if (s < 1) s = 1;
+      }
+      const long nbs = nb * s;
+      const double fill = (double)nbs / (double)(((nbs + 255) / 256) * 256);
+      if (fill >= env_int("AF_GEMM_PP_MINFILL", 70) * 0.01 && p.M >= 512) {
+        pl.tile = cand;
+        pl.splitk = s;
+        pl.halo_tw = 0;
+      }
+    }
   }
   const int ft = env_int("AF_GEMM_TILE", -1);
   if (ft >= 0 && ft < 4 && !(geglu && bn[ft] != 128)) pl.tile = ft;
-  if ((ft == 4 || ft == 5) && !pl.halo_tw && pl.splitk == 1) pl.tile = ft;
   const int fs = env_int("AF_GEMM_SPLITK", -1);
   if (fs >= 1 && batch == 1 && !geglu) pl.splitk = fs > KT ? KT : fs;
+  if (pl.splitk > 1) pl.halo_tw = 0;
   if (pl.splitk > 1) pl.ws_bytes = (size_t)pl.splitk * p.M * p.N * sizeof(float);
   {
     // grouped tile order: minimise  X_bytes * (NT / gn) + W_bytes * (MT / gm)  with gm * gn = workgroups resident
     // per XCD (32 CUs x blocks per CU)
     const int tbm = pl.halo_tw ? 128 : (pl.tile >= 4 ? 256 : bm[pl.tile]);
-    const int tbn = pl.halo_tw ? ((pl.tile == 0 || pl.tile == 1) ? 128 : 64) : (pl.tile == 5 ? 256 : pl.tile == 4 ? 128 : bn[pl.tile]);
+    const int tbn = pl.halo_tw ? ((pl.tile == 0 || pl.tile == 1) ? 128 : 64) : (pl.tile == 5 ? 160 : pl.tile == 4 ? 128 : bn[pl.tile]);
     const int MT = (p.M + tbm - 1) / tbm, NT = (p.N + tbn - 1) / tbn;
-    const int resident = 32 * ((tbm * tbn >= 128 * 128) ? 2 : 3);
+    const int resident = pl.tile >= 4 ? 32 : 32 * ((tbm * tbn >= 128 * 128) ? 2 : 3);
     const double xb = (double)p.M * (p.K / (p.ks * p.ks)) * (pl.halo_tw ? 1.5 : (double)(p.ks * p.ks) / (p.stride * p.stride));
     const double wb = (double)p.N * p.K;
     double bestc = 1e300;
@@ -1042,16 +1133,20 @@ static int launch_cfg(const ConvGemmParams& p, int batch, hipStream_t stream) {
   return use_dma ? launch_cfg2<T, BM, BN, true>(p, batch, stream) : launch_cfg2<T, BM, BN, false>(p, batch, stream);
 }
 
-template <typename T, int BN> static int launch_wide(const ConvGemmParams& p, int batch, hipStream_t stream) {
-  using C = WideCfg<BN>;
+template <int BN> static int launch_pp(const ConvGemmParams& p, hipStream_t stream) {
+  using C = PpCfg<BN>;
+  const bool gather = !(p.ks == 1 && p.pad == 0);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<T, BN>),
+    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_set = true;
   }
-  dim3 grid(((p.M + 255) / 256) * ((p.N + BN - 1) / BN), 1, batch);
-  hipLaunchKernelGGL((gemm_wide_kernel<T, BN>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  dim3 grid(((p.M + 255) / 256) * (p.N / BN), 1, p.splitk > 1 ? p.splitk : 1);
+  if (gather) hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, true>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  else hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, false>), grid, dim3(512), C::LDS_BYTES, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -1092,6 +1187,7 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   if (pl.splitk > 1 && !ws) pl.splitk = 1;  // no workspace supplied: fall back to one slice
   p.splitk = pl.splitk;
   p.ws = ws;
+  g_af_last_plan = pl;
   p.group_m = pl.group_m > 0 ? pl.group_m : 1;
   p.dbg_nobarrier = env_int("AF_DEBUG_NOBARRIER", 0);  // timing diagnostic only: results are WRONG when set
   AfProfScope prof(AF_K_CONV_GEMM, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K) * batch,
@@ -1104,8 +1200,15 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
     return rc;
   }
   switch (pl.tile) {
-    case 4: rc = launch_wide<T, 128>(p, batch, stream); break;
-    case 5: rc = launch_wide<T, 256>(p, batch, stream); break;
+    case 4:
+    case 5:
+      if constexpr (sizeof(T) == 2) {
+        rc = pl.tile == 4 ? launch_pp<128>(p, stream) : launch_pp<160>(p, stream);
+      } else {
+        af_set_error_msg("conv_gemm: ping-pong tiles are bf16 only");
+        return -1;
+      }
+      break;
     case 0: rc = launch_cfg<T, 128, 128>(p, batch, stream); break;
     case 1: rc = launch_cfg<T, 64, 128>(p, batch, stream); break;
     case 2: rc = launch_cfg<T, 128, 64>(p, batch, stream); break;

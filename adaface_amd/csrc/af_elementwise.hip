@@ -326,7 +326,7 @@ INST(float)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int geglu_perm(int n, int half) {
   const int j = n < half ? n : n - half;
-  return (j >> 5) * 64 + (n < half ? 0 : 32) + (j & 31);
+  return (j >> 4) * 32 + (n < half ? 0 : 16) + (j & 15);
 }
 template <typename T>
 __global__ void repack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int cin,

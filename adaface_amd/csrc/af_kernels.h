@@ -38,8 +38,11 @@ template <typename T> int af_launch_to_uint8(const void* x, int ld, uint8_t* y, 
 int af_launch_nchw_to_uint8(const float* x, uint8_t* y, int B, int HW, hipStream_t s);
 
 // weight repack (device): src fp32 [rows][cin][ks][ks] -> dst T rows [row_off + perm(n)][ks*ks*cin_pad]
-//   perm: 0 identity, 1 GEGLU interleave (value/gate groups of 32, half = rows/2)
+//   perm: 0 identity, 1 GEGLU interleave (value/gate groups of 16, half = rows/2)
 template <typename T>
 int af_launch_repack_weight(const float* src, void* dst, int rows, int cin, int cin_pad, int ks, int ldw, int row_off,
                             int perm, hipStream_t s);
 int af_launch_permute_bias(const float* src, float* dst, int rows, int perm, hipStream_t s);
+
+// plan of the most recent af_launch_conv_gemm (diagnostics, af_last_gemm_plan)
+extern AfGemmPlan g_af_last_plan;

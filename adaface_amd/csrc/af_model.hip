@@ -341,7 +341,7 @@ static int make_xfmr(Builder& b, const std::string& prefix, int C, int heads, in
     b.weight_slot(p + ".attn2.to_k.weight", t.kv2, inner, 0, 0, false);
     b.weight_slot(p + ".attn2.to_v.weight", t.kv2, inner, inner, 0, false);
     b.make_conv(t.out2, p + ".attn2.to_out.0", inner, inner, 1, true, false);
-    // ff: GEGLU proj (value|gate rows interleaved in groups of 32) + out linear
+    // ff: GEGLU proj (value|gate rows interleaved in groups of 16) + out linear
     b.alloc_linear(t.ff1, inner, 8 * inner, 1, false);
     t.ff1.geglu = true;
     b.weight_slot(p + ".ff.net.0.proj.weight", t.ff1, 8 * inner, 0, 1, false);
@@ -1247,6 +1247,12 @@ int af_prof_reset(void) {
   g_prof_recs.clear();
   g_prof_pool_used = 0;
   return 0;
+}
+int af_last_gemm_plan(int* tile, int* splitk, int* halo_tw) {
+  if (tile) *tile = g_af_last_plan.tile;
+  if (splitk) *splitk = g_af_last_plan.splitk;
+  if (halo_tw) *halo_tw = g_af_last_plan.halo_tw;
+  return AF_OK;
 }
 int af_prof_collect(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes) {
   for (int c = 0; c < n_classes; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; bytes[c] = 0; }

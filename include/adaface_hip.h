@@ -110,6 +110,10 @@ int64_t af_arena_bytes(af_handle* h);
 int af_prof_enable(int class_mask); /* bit c set = time class c; 0 = off */
 int af_prof_reset(void);
 int af_prof_collect(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes);
+/* diagnostics: the tiling the most recent conv / linear launch of this process used.
+ * tile: 0-3 = 128x128 / 64x128 / 128x64 / 64x64 four-wave tiles, 4 / 5 = 256x128 / 256x160 eight-wave ping-pong tiles;
+ * halo_tw != 0: LDS-halo 3x3 kernel.  The parity tests use it to assert which kernel they exercised. */
+int af_last_gemm_plan(int* tile, int* splitk, int* halo_tw);
 
 /* ---- operator-level entry points (parity tests; reference layouts, fp32 device tensors) ----
  * Each converts to the internal NHWC `dtype` layout, runs the same kernel the model

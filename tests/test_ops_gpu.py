@@ -130,6 +130,78 @@ def test_conv2d(gpu, report, dtype, B, Cin, H, W, Cout, ks, stride, up, bias, re
     _cmp(report, f"conv{ks}x{ks} {Cin}->{Cout}@{H}x{W} s{stride} up{int(up)}", got, ref, dtype)
 
 
+def _last_plan():
+    import ctypes as C
+    from adaface_amd import _lib
+    t, s, h = C.c_int(), C.c_int(), C.c_int()
+    _lib.load().af_last_gemm_plan(C.byref(t), C.byref(s), C.byref(h))
+    return t.value, s.value, h.value
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,ks,stride,up,bias,res,splitk", [
+    (2, 320, 32, 32, 320, 3, 1, False, True, True, 1),    # gather, 2 N tiles of 160, residual
+    (1, 128, 24, 24, 160, 3, 1, False, True, False, 1),   # M = 576: ragged last M tile (rows >= M read as zero)
+    (2, 64, 32, 32, 160, 3, 2, False, True, False, 1),    # stride 2, K = 9 tiles of one tap each
+    (1, 128, 16, 16, 320, 3, 1, True, False, True, 1),    # nearest-2x upsample folded into the gather
+    (2, 960, 16, 16, 640, 1, 1, False, True, False, 1),   # 1x1: plain-GEMM variant (no gather)
+    (2, 1280, 16, 16, 1280, 3, 1, False, True, True, 3),  # split-K slabs + reduce (60 tiles per slice)
+    (1, 256, 32, 32, 256, 3, 1, False, True, False, 1),   # VAE width: N % 128 == 0 only -> 256x128 tile
+    (2, 64, 16, 16, 160, 3, 1, False, True, False, 1),    # one K tile per tap (KT = 9)
+    (2, 64, 16, 16, 160, 1, 1, False, True, False, 1),    # KT = 1: prologue-only pipeline
+    (2, 128, 16, 16, 160, 1, 1, False, True, False, 1),   # KT = 2
+])
+def test_conv2d_pingpong(gpu, report, monkeypatch, B, Cin, H, W, Cout, ks, stride, up, bias, res, splitk):
+    """The eight-wave 256x{160,128} ping-pong kernel (conv_gemm_pp_kernel), forced regardless of grid fill."""
+    from adaface_amd import ops
+    monkeypatch.setenv("AF_GEMM_PP_MINFILL", "0")
+    if splitk > 1:
+        monkeypatch.setenv("AF_GEMM_SPLITK", str(splitk))
+    dtype = "bf16"
+    g = torch.Generator().manual_seed(Cin + Cout + H + ks + 1)
+    x = _q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = _q(torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks), dtype)
+    b = torch.randn(Cout, generator=g) * 0.1 if bias else None
+    xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    ref = F.conv2d(xi, w, b, stride=stride, padding=ks // 2)
+    r = _q(torch.randn(ref.shape, generator=g), dtype) if res else None
+    if res:
+        ref = ref + r
+    got = ops.conv2d(x.to(gpu), w.to(gpu), None if b is None else b.to(gpu), stride=stride, upsample=up,
+                     residual=None if r is None else r.to(gpu), dtype=dtype)
+    tile, sk, halo = _last_plan()
+    assert tile in (4, 5) and halo == 0 and (splitk == 1 or sk == splitk), (tile, sk, halo)  # planner may slice K itself
+    _cmp(report, f"pp conv{ks}x{ks} {Cin}->{Cout}@{H}x{W} s{stride} up{int(up)} sk{splitk}", got, ref, dtype)
+
+
+@pytest.mark.parametrize("M,K,N,bias,res,geglu", [
+    (4096, 320, 320, True, True, False), (1000, 640, 1920, False, False, False), (4096, 1280, 320, True, True, False),
+    (512, 64, 160, True, False, False), (4096, 320, 1280, True, False, True), (700, 640, 2560, True, False, True),
+    (1024, 1280, 5120, False, False, True),
+])
+def test_linear_pingpong(gpu, report, monkeypatch, M, K, N, bias, res, geglu):
+    """Linear / GEGLU through the ping-pong kernel (GEGLU: 256x128 tile, value|gate interleaved in 16-row groups)."""
+    from adaface_amd import ops
+    monkeypatch.setenv("AF_GEMM_PP_MINFILL", "0")
+    dtype = "bf16"
+    g = torch.Generator().manual_seed(M + K + N + 1)
+    x = _q(torch.randn(M, K, generator=g), dtype)
+    rows = 2 * N if geglu else N
+    w = _q(torch.randn(rows, K, generator=g) / math.sqrt(K), dtype)
+    b = torch.randn(rows, generator=g) * 0.1 if bias else None
+    r = _q(torch.randn(M, N, generator=g), dtype) if res else None
+    ref = F.linear(x, w, b)
+    if geglu:
+        val, gate = ref.chunk(2, dim=-1)
+        ref = val * F.gelu(gate)
+    if res:
+        ref = ref + r
+    got = ops.linear(x.to(gpu), w.to(gpu), None if b is None else b.to(gpu), None if r is None else r.to(gpu),
+                     geglu=geglu, dtype=dtype)
+    tile, sk, halo = _last_plan()
+    assert tile == (4 if geglu else 5) and halo == 0, (tile, sk, halo)
+    _cmp(report, f"pp linear {M}x{K}->{N}{' geglu' if geglu else ''}", got, ref, dtype)
+
+
 def _ref_attention(q, k, v, heads):
     B, N, C = q.shape
     dh = C // heads
