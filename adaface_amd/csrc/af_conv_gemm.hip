@@ -621,6 +621,15 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
   std::integral_constant<int, 0> U0;
   std::integral_constant<int, 1> U1;
 
+  // bias of this lane's output channels (GEGLU: value and gate rows), fetched now so the main loop hides the latency
+  const int cl = 4 * (lane >> 4);
+  float4 bias_r[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    bias_r[i] = float4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && p.splitk <= 1) bias_r[i] = *reinterpret_cast<const float4*>(p.bias + n0 + g * C::HN + i * 16 + cl);
+  }
+
   // ---- prologue: tile 0 (group 1 also tile 1) in flight; group 1's part of tile 0 landed ----
   stage(0);
   if (g == 1) {
@@ -658,69 +667,118 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
   if (g == 0) __builtin_amdgcn_s_barrier();
 
   // ------------------------------- epilogue -------------------------------
-  // two passes of 128 rows: waves with (wq >> 1) == pass put their accumulators into an fp32 LDS tile, then all 512
-  // threads walk it in 8-column vectors (a wave covers whole contiguous rows)
+  // GEGLU is evaluated in registers by all eight waves first (value block 2k, gate block 2k+1 of the same lane);
+  // then two passes of 128 rows: waves with (wq >> 1) == pass put their accumulators into an fp32 LDS tile and all
+  // 512 threads walk it in 8-column vectors (a wave covers whole contiguous rows).  Every load of a pass (LDS tile,
+  // time-embedding row, residual) is issued before the first store so their latencies overlap.
   float* et = reinterpret_cast<float*>(smem);
   const bool geglu = p.epilogue == AF_EPI_GEGLU;
-  const int BNo = geglu ? BN / 2 : BN;
+  if (geglu) {
+    if constexpr ((NI & 1) == 0) {
+      // packed weight rows [32k, 32k+16) are "value", [32k+16, 32k+32) "gate" (bias packed alike)
+#pragma unroll
+      for (int k2 = 0; k2 < NI / 2; ++k2) {
+        const float* bvp = reinterpret_cast<const float*>(&bias_r[2 * k2]);
+        const float* bgp = reinterpret_cast<const float*>(&bias_r[2 * k2 + 1]);
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float val = acc[2 * k2][j][e] * p.alpha + bvp[e];
+            const float gat = acc[2 * k2 + 1][j][e] * p.alpha + bgp[e];
+            acc[k2][j][e] = val * gelu_erf_f(gat);   // block k2 <= 2 k2: already consumed
+          }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float* bp = reinterpret_cast<const float*>(&bias_r[i]);
+#pragma unroll
+      for (int j = 0; j < MI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = acc[i][j][e] * p.alpha + bp[e];
+    }
+  }
+  const int BNo = geglu ? BN / 2 : BN;              // columns of the staged tile
+  const int HNo = geglu ? C::HN / 2 : C::HN;        // ... per wave group
   const int tpr = BNo >> 3;
   const int ncol0 = geglu ? (n0 >> 1) : n0;
   const int Nvalid = geglu ? (p.N >> 1) : p.N;
   T* __restrict__ out = reinterpret_cast<T*>(p.out);
   const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
   const T* __restrict__ rowb = reinterpret_cast<const T*>(p.rowbias);
-  const float* __restrict__ bias = geglu ? nullptr : p.bias;
   float* slab = p.splitk > 1 ? reinterpret_cast<float*>(p.ws) + (long)zk * p.M * p.N : nullptr;
+  constexpr int ITEMS = BN / 32;                    // 8-column vectors per thread and pass (GEGLU: half of them)
+  const int nitems = geglu ? ITEMS / 2 : ITEMS;
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     if (pass) __syncthreads();
     if ((wq >> 1) == pass) {
       const int rbase = (wq & 1) * 64 + (lane & 15);
-      const int cl = 4 * (lane >> 4);
-      if (geglu) {
-        if constexpr ((NI & 1) == 0) {
-          // packed weight rows [32k, 32k+16) are "value", [32k+16, 32k+32) "gate": blocks 2k / 2k+1 of this wave
+      const int nblk = geglu ? NI / 2 : NI;
 #pragma unroll
-          for (int j = 0; j < MI; ++j)
+      for (int j = 0; j < MI; ++j)
 #pragma unroll
-            for (int k2 = 0; k2 < NI / 2; ++k2) {
-              const int nv = n0 + g * C::HN + k2 * 32 + cl;   // packed column of the value (bias is packed alike)
-              float4 o;
-              float* op = reinterpret_cast<float*>(&o);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                float val = acc[2 * k2][j][e] * p.alpha, gat = acc[2 * k2 + 1][j][e] * p.alpha;
-                if (p.bias) { val += p.bias[nv + e]; gat += p.bias[nv + 16 + e]; }
-                op[e] = val * gelu_erf_f(gat);
-              }
-              *reinterpret_cast<float4*>(et + (rbase + j * 16) * C::EPI_LD + g * (C::HN / 2) + k2 * 16 + cl) = o;
-            }
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < MI; ++j)
-#pragma unroll
-          for (int i = 0; i < NI; ++i) {
-            float4 o;
-            o.x = acc[i][j][0] * p.alpha; o.y = acc[i][j][1] * p.alpha;
-            o.z = acc[i][j][2] * p.alpha; o.w = acc[i][j][3] * p.alpha;
-            *reinterpret_cast<float4*>(et + (rbase + j * 16) * C::EPI_LD + g * C::HN + i * 16 + cl) = o;
-          }
-      }
+        for (int i = 0; i < NI; ++i)
+          if (i < nblk)
+            *reinterpret_cast<f32x4*>(et + (rbase + j * 16) * C::EPI_LD + g * HNo + i * 16 + cl) = acc[i][j];
     }
     __syncthreads();
-    for (int idx = tid; idx < 128 * tpr; idx += 512) {
+    // ---- gather phase: everything this thread needs for its ITEMS vectors ----
+    float v[ITEMS][8];
+    int im[ITEMS], in_[ITEMS];
+    Quad<T> rq[ITEMS][2], bq[ITEMS][2];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * 512;
       const int row = idx / tpr, c8 = (idx - row * tpr) * 8;
       const int m = m0 + pass * 128 + row, n = ncol0 + c8;
-      if (m >= p.M || n >= Nvalid) continue;
+      const bool ok = it < nitems && m < p.M && n < Nvalid;
+      im[it] = ok ? m : -1;
+      in_[it] = n;
+      if (!ok) continue;
       const float4 a = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8);
       const float4 b4 = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8 + 4);
+      v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
+      v[it][4] = b4.x; v[it][5] = b4.y; v[it][6] = b4.z; v[it][7] = b4.w;
+      if (slab) continue;
+      if (rowb) {
+        const T* rp = rowb + (long)(m / HoWo) * p.ldrb + n;
+        bq[it][0].load(rp);
+        bq[it][1].load(rp + 4);
+      }
+      if (res) {
+        const T* rp = res + (long)m * p.ldr + n;
+        rq[it][0].load(rp);
+        rq[it][1].load(rp + 4);
+      }
+    }
+    // ---- combine + store ----
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int m = im[it], n = in_[it];
+      if (m < 0) continue;
       if (slab) {
-        *reinterpret_cast<float4*>(slab + (long)m * p.N + n) = a;
-        if (n + 4 < Nvalid) *reinterpret_cast<float4*>(slab + (long)m * p.N + n + 4) = b4;
-      } else {
-        float v[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
-        epi_store8<T>(p, v, m, rowb ? m / HoWo : 0, n, min(8, Nvalid - n), out, res, rowb, bias);
+        *reinterpret_cast<float4*>(slab + (long)m * p.N + n) = float4{v[it][0], v[it][1], v[it][2], v[it][3]};
+        *reinterpret_cast<float4*>(slab + (long)m * p.N + n + 4) = float4{v[it][4], v[it][5], v[it][6], v[it][7]};
+        continue;
+      }
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq) {
+        float* vv = v[it] + 4 * hq;
+        if (rowb) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] += to_f32<T>(bq[it][hq].e[e]);
+        }
+        if (res) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] += to_f32<T>(rq[it][hq].e[e]);
+        }
+        Quad<T> o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.e[e] = from_f32<T>(vv[e]);
+        o.store(out + (long)m * p.ldo + n + 4 * hq);
       }
     }
   }
@@ -1057,14 +1115,19 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
     int cand = -1;
     if (!geglu && p.N % 160 == 0) cand = 5;
     else if (p.N % 128 == 0) cand = 4;
+    // (GEGLU with few K tiles is bound by its epilogue -- ~6k VALU cycles of erf per SIMD against 7.5k cycles of main
+    // loop at K = 320 -- which one workgroup per CU cannot overlap with another tile's MFMAs; with the register-phase
+    // epilogue it still measures 10-18 % ahead of the four-wave kernel, so the threshold defaults to 0)
+    if (geglu && KT < env_int("AF_GEMM_PP_GEGLU_MINKT", 0)) cand = -1;
     if (cand >= 0) {
       const int tbn = cand == 5 ? 160 : 128;
       const long nb = (long)((p.M + 255) / 256) * (p.N / tbn);
       int s = 1;
       if (!geglu && nb < 208) {
-        // slice K until the 256 CUs are covered; every slice keeps >= 8 K tiles
+        // slice K until the 256 CUs are covered; every slice keeps >= 16 K tiles (shorter slices lose more in the
+        // pipeline prologue and the reduce pass than the extra workgroups gain)
         s = (int)((256 + nb / 2) / nb);
-        if (s > KT / 8) s = KT / 8;
+        if (s > KT / 16) s = KT / 16;
         if (s > 16) s = 16;
         if (s < 1) s = 1;
       }

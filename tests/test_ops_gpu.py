@@ -182,6 +182,7 @@ def test_linear_pingpong(gpu, report, monkeypatch, M, K, N, bias, res, geglu):
     """Linear / GEGLU through the ping-pong kernel (GEGLU: 256x128 tile, value|gate interleaved in 16-row groups)."""
     from adaface_amd import ops
     monkeypatch.setenv("AF_GEMM_PP_MINFILL", "0")
+    monkeypatch.setenv("AF_GEMM_PP_GEGLU_MINKT", "0")
     dtype = "bf16"
     g = torch.Generator().manual_seed(M + K + N + 1)
     x = _q(torch.randn(M, K, generator=g), dtype)
