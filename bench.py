@@ -176,7 +176,7 @@ def main():
                     traffic = json.loads(tf.read_text()).get("conv_gemm_hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roof = {"kernel": "conv_gemm_kernel (implicit-GEMM conv3x3 / conv1x1 / linear, all shapes)",
+            roof = {"kernel": "conv/linear class: conv_gemm_pp_kernel (256x160 ping-pong) + conv_gemm_kernel + splitk_reduce, all shapes",
                     "bound": "mfma", "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                     "frac": ach / peak, "traffic": traffic,
                     "flops_per_launch": flops[0] / launches[0], "avg_launch_us": 1e3 * ms[0] / launches[0],
