@@ -64,6 +64,7 @@ _SIGS = [
     ("af_arena_bytes", C.c_int64, [_P]),
     ("af_prof_enable", C.c_int, [C.c_int]),
     ("af_prof_reset", C.c_int, []),
+    ("af_prof_set_stride", C.c_int, [C.c_int]),
     ("af_last_gemm_plan", C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("af_prof_collect", C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]),

@@ -30,12 +30,17 @@ void af_set_error_msg(const char* fmt, ...);
 // per-kernel-class HIP-event profiling (enabled only by bench.py; see af_prof_* in adaface_hip.h)
 enum { AF_K_CONV_GEMM = 0, AF_K_ATTENTION = 1, AF_K_GROUPNORM = 2, AF_K_LAYERNORM = 3, AF_K_OTHER = 4, AF_K_COUNT = 5 };
 extern int g_af_prof_enabled;
+extern int g_af_prof_stride;              // bracket only every stride-th launch of a class (>= 1)
+extern long g_af_prof_seen[AF_K_COUNT];   // launches seen per class since af_prof_reset
 void af_prof_begin_impl(int cls, hipStream_t s, double flops, double bytes);
 void af_prof_end_impl(hipStream_t s);
 struct AfProfScope {
   hipStream_t s;
   bool on;
   AfProfScope(int cls, hipStream_t s_, double flops, double bytes) : s(s_), on(((g_af_prof_enabled >> cls) & 1) != 0) {
+    // an event pair costs ~9 us of stream time on MI355X (measured: bracketing every GEMM and attention launch slowed
+    // the 50-step batch by 10 %), so the bench samples every stride-th launch of a class instead of all of them
+    if (on) on = (g_af_prof_seen[cls]++ % g_af_prof_stride) == 0;
     if (on) af_prof_begin_impl(cls, s, flops, bytes);
   }
   ~AfProfScope() {

@@ -41,6 +41,8 @@ void af_set_error_msg(const char* fmt, ...) {
 // HIP-event profiling per kernel class (bench.py's roofline leg)
 // ----------------------------------------------------------------------------
 int g_af_prof_enabled = 0;
+int g_af_prof_stride = 1;
+long g_af_prof_seen[AF_K_COUNT] = {0, 0, 0, 0, 0};
 namespace {
 struct ProfRec {
   hipEvent_t start, stop;
@@ -1246,7 +1248,13 @@ int af_prof_enable(int class_mask) {
 int af_prof_reset(void) {
   g_prof_recs.clear();
   g_prof_pool_used = 0;
+  for (int c = 0; c < AF_K_COUNT; ++c) g_af_prof_seen[c] = 0;
   return 0;
+}
+int af_prof_set_stride(int every) {
+  if (every < 1) { af_set_error_msg("af_prof_set_stride: stride must be >= 1"); return AF_ERR_INVALID; }
+  g_af_prof_stride = every;
+  return AF_OK;
 }
 int af_last_gemm_plan(int* tile, int* splitk, int* halo_tw) {
   if (tile) *tile = g_af_last_plan.tile;

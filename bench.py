@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event roofline leg")
+    ap.add_argument("--event-stride", type=int, default=7,
+                    help="HIP-event bracket every n-th GEMM / attention launch inside the timed region (1 = all)")
     return ap.parse_args()
 
 
@@ -140,6 +142,7 @@ def main():
     timing = not args.no_kernel_timing
     if timing:
         lib.af_prof_reset()
+        lib.af_prof_set_stride(args.event_stride)  # sample: an event pair per launch would cost ~10 % of the step
         lib.af_prof_enable(0b00011)  # conv_gemm + attention
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -180,7 +183,7 @@ def main():
                     "bound": "mfma", "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                     "frac": ach / peak, "traffic": traffic,
                     "flops_per_launch": flops[0] / launches[0], "avg_launch_us": 1e3 * ms[0] / launches[0],
-                    "launches": int(launches[0])}
+                    "launches": int(launches[0]), "sampled_every": args.event_stride}
 
     if rank == 0:
         images = world * B * args.steps

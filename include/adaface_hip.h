@@ -109,6 +109,9 @@ int64_t af_arena_bytes(af_handle* h);
  * sums elapsed ms, launch counts and the ALGORITHMIC flops / bytes of those launches per class. */
 int af_prof_enable(int class_mask); /* bit c set = time class c; 0 = off */
 int af_prof_reset(void);
+/* time only every `every`-th launch of a class (default 1 = all).  An event pair costs ~9 us of stream time, so
+ * bench.py samples (every = 7) inside its timed region; sums and launch counts then cover the sampled launches. */
+int af_prof_set_stride(int every);
 int af_prof_collect(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes);
 /* diagnostics: the tiling the most recent conv / linear launch of this process used.
  * tile: 0-3 = 128x128 / 64x128 / 128x64 / 64x64 four-wave tiles, 4 / 5 = 256x128 / 256x160 eight-wave ping-pong tiles;
