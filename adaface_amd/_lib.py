@@ -32,6 +32,7 @@ class AfConfig(C.Structure):
         ("vae_ch", C.c_int), ("vae_out_ch", C.c_int), ("vae_num_res_blocks", C.c_int),
         ("vae_z_channels", C.c_int), ("vae_embed_dim", C.c_int),
         ("n_vae_ch_mult", C.c_int), ("vae_ch_mult", C.c_int * 8),
+        ("build_vae_encoder", C.c_int), ("vae_in_channels", C.c_int),
     ]
 
 
@@ -64,6 +65,8 @@ _SIGS = [
     ("af_arena_bytes", C.c_int64, [_P]),
     ("af_prof_enable", C.c_int, [C.c_int]),
     ("af_prof_reset", C.c_int, []),
+    ("af_vae_encode", C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    ("af_posterior_sample", C.c_int, [_P, _P, C.c_float, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("af_prof_set_stride", C.c_int, [C.c_int]),
     ("af_last_gemm_plan", C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("af_prof_collect", C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),

@@ -142,6 +142,21 @@ __global__ void lincomb_kernel(float* __restrict__ out, long n, const float* __r
   }
 }
 
+// DiagonalGaussianDistribution.sample (distributions.py:27-37) + the scale_factor of get_first_stage_encoding
+__global__ void posterior_sample_kernel(const float* __restrict__ mom, const float* __restrict__ noise, float scale,
+                                        float* __restrict__ z, int Cn, long HW, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / (Cn * HW), r = i - b * (Cn * HW);
+    const float mean = mom[b * 2 * Cn * HW + r];
+    float v = mean;
+    if (noise) {
+      const float lv = fminf(fmaxf(mom[b * 2 * Cn * HW + Cn * HW + r], -30.0f), 20.0f);
+      v = mean + expf(0.5f * lv) * noise[i];
+    }
+    z[i] = scale * v;
+  }
+}
+
 // row softmax in place over fp32-accumulated T rows: x[row][0..n) (VAE AttnBlock)
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(T* __restrict__ x, int ld, int ncols, long rows) {
@@ -278,6 +293,13 @@ int af_launch_ddim_step(const float* x, const float* eps_c, const float* eps_u, 
 int af_launch_lincomb(float* out, long n, const float* x0, float w0, const float* x1, float w1, const float* x2, float w2,
                       const float* x3, float w3, int mode, hipStream_t s) {
   hipLaunchKernelGGL(lincomb_kernel, EW_GRID(n), dim3(256), 0, s, out, n, x0, w0, x1, w1, x2, w2, x3, w3, mode);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int af_launch_posterior_sample(const float* mom, const float* noise, float scale, float* z, int B, int Cn, long HW,
+                               hipStream_t s) {
+  const long total = (long)B * Cn * HW;
+  hipLaunchKernelGGL(posterior_sample_kernel, EW_GRID(total), dim3(256), 0, s, mom, noise, scale, z, Cn, HW, total);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -29,6 +29,8 @@ int af_launch_copy_channels(const void* src, int lds_, void* dst, int ldd, int o
 int af_launch_ddim_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, long n,
                         float guidance, float a_t, float a_prev, float sqrt_one_minus_at, float sigma_t,
                         float temperature, float* x_prev, float* pred_x0, hipStream_t s);
+int af_launch_posterior_sample(const float* mom, const float* noise, float scale, float* z, int B, int Cn, long HW,
+                               hipStream_t s);
 int af_launch_lincomb(float* out, long n, const float* x0, float w0, const float* x1, float w1, const float* x2, float w2,
                       const float* x3, float w3, int mode, hipStream_t s);
 template <typename T> int af_launch_softmax_rows(void* x, int ld, int ncols, long rows, hipStream_t s);

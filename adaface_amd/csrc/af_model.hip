@@ -205,6 +205,13 @@ struct af_handle {
   struct VLevel { std::vector<int> blocks; int up = -1; };
   int vmid1 = -1, vmid2 = -1;
   std::vector<VLevel> vlevels;  // index = i_level
+  // VAE encoder (VLevel::up = index into edown)
+  Linear quant_conv, enc_conv_in, enc_conv_out;
+  Norm enc_norm_out;
+  VaeAttnW eattn;
+  std::vector<Linear> edown;
+  int emid1 = -1, emid2 = -1;
+  std::vector<VLevel> elevels;
 
   // runtime state
   Arena arena;
@@ -550,6 +557,51 @@ static int build_vae(Builder& b) {
   return b.rc;
 }
 
+static void make_vae_attn(Builder& b, VaeAttnW& a, const std::string& p, int C) {
+  a.C = C;
+  b.make_norm(a.gn, p + ".norm", C, 1e-6f);
+  b.alloc_linear(a.qkv, C, 3 * C, 1, false);
+  a.qkv.bias = b.alloc_vec(3 * C);
+  const char* nm[3] = {".q", ".k", ".v"};
+  for (int i = 0; i < 3; ++i) {
+    b.weight_slot(p + nm[i] + ".weight", a.qkv, C, i * C, 0, true);
+    b.vec_slot(p + nm[i] + ".bias", a.qkv.bias + i * C, C);
+  }
+  b.make_conv(a.proj_out, p + ".proj_out", C, C, 1);
+}
+
+// mirrors Encoder.__init__ (model.py:408-470) + quant_conv (autoencoder.py:304)
+static int build_vae_encoder(Builder& b) {
+  af_handle* h = b.h;
+  const af_config& c = h->cfg;
+  const std::string P = "first_stage_model.";
+  const int nres = c.n_vae_ch_mult;
+  b.make_conv(h->enc_conv_in, P + "encoder.conv_in", c.vae_in_channels, c.vae_ch, 3, true, true, true);
+  int block_in = c.vae_ch;
+  h->elevels.resize(nres);
+  for (int lvl = 0; lvl < nres; ++lvl) {
+    const int block_out = c.vae_ch * c.vae_ch_mult[lvl];
+    const std::string pl = P + "encoder.down." + std::to_string(lvl);
+    for (int i = 0; i < c.vae_num_res_blocks; ++i) {
+      h->elevels[lvl].blocks.push_back(make_vae_resblock(b, pl + ".block." + std::to_string(i), block_in, block_out));
+      block_in = block_out;
+    }
+    if (lvl != nres - 1) {
+      Linear d;
+      b.make_conv(d, pl + ".downsample.conv", block_in, block_in, 3);
+      h->edown.push_back(d);
+      h->elevels[lvl].up = (int)h->edown.size() - 1;
+    }
+  }
+  h->emid1 = make_vae_resblock(b, P + "encoder.mid.block_1", block_in, block_in);
+  make_vae_attn(b, h->eattn, P + "encoder.mid.attn_1", block_in);
+  h->emid2 = make_vae_resblock(b, P + "encoder.mid.block_2", block_in, block_in);
+  b.make_norm(h->enc_norm_out, P + "encoder.norm_out", block_in, 1e-6f);
+  b.make_conv(h->enc_conv_out, P + "encoder.conv_out", block_in, 2 * c.vae_z_channels, 3);
+  b.make_conv(h->quant_conv, P + "quant_conv", 2 * c.vae_z_channels, 2 * c.vae_embed_dim, 1, true, true, true);
+  return b.rc;
+}
+
 // ----------------------------------------------------------------------------
 // op runner: thin typed dispatch + arena allocation
 // ----------------------------------------------------------------------------
@@ -577,8 +629,11 @@ struct Runner {
   }
 
   // conv / linear.  out must be preallocated.  up: nearest 2x before the conv.
+  // pad < 0: the layer's symmetric ks/2.  pad = 0 with stride 2 on an even map is the VAE Downsample: the reference
+  // pads one zero row / column at the bottom / right only (model.py:73-77), which is exactly what the gather's
+  // bounds check returns for iy == Hi / ix == Wi
   int conv(const Linear& L, const Act& x, Act& out, int stride, int up, const Act* residual, const void* rowbias,
-           int ldrb, int n_valid = -1) {
+           int ldrb, int n_valid = -1, int pad = -1) {
     AF_TRY(check(out));
     ConvGemmParams p;
     memset(&p, 0, sizeof(p));
@@ -590,7 +645,7 @@ struct Runner {
     p.up = up;
     p.Hi = x.H << up; p.Wi = x.W << up;
     p.Ho = out.H; p.Wo = out.W;
-    p.ks = L.ks; p.stride = stride; p.pad = L.ks / 2;
+    p.ks = L.ks; p.stride = stride; p.pad = pad >= 0 ? pad : L.ks / 2;
     p.W = L.w; p.ldw = L.ldw; p.Wrows = L.rows_pad;
     p.M = (int)out.npix();
     p.N = n_valid > 0 ? n_valid : round_up(L.cout, 4);
@@ -905,6 +960,10 @@ static int unet_forward_impl(af_handle* h, hipStream_t s, const float* x_dev, co
 static int run_vae_attn(Runner& R, const VaeAttnW& w, const Act& x, Act& out) {
   const size_t mk = R.A.mark();
   const int B = x.B, N = x.H * x.W, C = w.C, dt = R.dt;
+  if (N % bk_of(dt) != 0) {   // the P·V GEMM contracts over the N positions
+    af_set_error_msg("VAE mid-block attention: H*W = %d positions must be a multiple of %d", N, bk_of(dt));
+    return AF_ERR_INVALID;
+  }
   Act g = R.alloc_act(B, x.H, x.W, C);
   AF_TRY(R.groupnorm(w.gn, x, g, 0));
   Act qkv = R.alloc_act(B, x.H, x.W, 3 * C);
@@ -1003,6 +1062,56 @@ static int vae_decode_impl(af_handle* h, hipStream_t s, const float* z_dev, floa
   return 0;
 }
 
+// AutoencoderKL.encode (autoencoder.py:324-326): Encoder.forward (model.py:472-499) + quant_conv
+static int vae_encode_impl(af_handle* h, hipStream_t s, const float* x_dev, float* moments_dev, int B, int H, int W) {
+  Runner R(h, s);
+  const af_config& c = h->cfg;
+  const int dt = h->dtype;
+  R.A.off = 0;
+  Act x = R.alloc_act(B, H, W, c.vae_in_channels, h->enc_conv_in.cin_pad);
+  AF_TRY(R.check(x));
+  if (!R.dry)
+    AF_TRY(DISPATCH(dt, af_launch_nchw_to_nhwc<bf16>(x_dev, x.p, B, c.vae_in_channels, H * W, x.ld, 1.0f, s),
+                    af_launch_nchw_to_nhwc<float>(x_dev, x.p, B, c.vae_in_channels, H * W, x.ld, 1.0f, s)));
+  Act hcur = R.alloc_act(B, H, W, h->enc_conv_in.cout);
+  AF_TRY(R.conv(h->enc_conv_in, x, hcur, 1, 0, nullptr, nullptr, 0));
+  auto res = [&](int ri) -> int {
+    const ResBlockW& w = h->vres[ri];
+    Act out = R.alloc_act(B, hcur.H, hcur.W, w.cout);
+    AF_TRY(run_resblock(R, w, hcur, out, nullptr, 0));
+    hcur = out;
+    return 0;
+  };
+  for (size_t lvl = 0; lvl < h->elevels.size(); ++lvl) {
+    for (int ri : h->elevels[lvl].blocks) AF_TRY(res(ri));
+    if (h->elevels[lvl].up >= 0) {
+      Act out = R.alloc_act(B, hcur.H / 2, hcur.W / 2, hcur.C);
+      AF_TRY(R.conv(h->edown[h->elevels[lvl].up], hcur, out, 2, 0, nullptr, nullptr, 0, -1, /*pad=*/0));
+      hcur = out;
+    }
+  }
+  AF_TRY(res(h->emid1));
+  {
+    Act out = R.alloc_act(B, hcur.H, hcur.W, hcur.C);
+    AF_TRY(run_vae_attn(R, h->eattn, hcur, out));
+    hcur = out;
+  }
+  AF_TRY(res(h->emid2));
+  Act g = R.alloc_act(B, hcur.H, hcur.W, hcur.C);
+  AF_TRY(R.groupnorm(h->enc_norm_out, hcur, g, 1));
+  Act m1 = R.alloc_act(B, hcur.H, hcur.W, 2 * c.vae_z_channels, h->quant_conv.cin_pad);
+  AF_TRY(R.check(m1));
+  if (!R.dry) HIP_CHECK_RET(hipMemsetAsync(m1.p, 0, (size_t)m1.npix() * m1.ld * esize(dt), s));
+  AF_TRY(R.conv(h->enc_conv_out, g, m1, 1, 0, nullptr, nullptr, 0));
+  const int oc = 2 * c.vae_embed_dim;
+  Act m2 = R.alloc_act(B, hcur.H, hcur.W, oc, round_up(oc, 4));
+  AF_TRY(R.conv(h->quant_conv, m1, m2, 1, 0, nullptr, nullptr, 0));
+  if (!R.dry)
+    AF_TRY(DISPATCH(dt, af_launch_nhwc_to_nchw<bf16>(m2.p, moments_dev, B, oc, m2.H * m2.W, m2.ld, s),
+                    af_launch_nhwc_to_nchw<float>(m2.p, moments_dev, B, oc, m2.H * m2.W, m2.ld, s)));
+  return 0;
+}
+
 // ============================================================================
 // C ABI
 // ============================================================================
@@ -1032,6 +1141,11 @@ int af_create(int device_id, const af_config* cfg, af_handle** out) {
     if (cfg->n_vae_ch_mult <= 0 || cfg->n_vae_ch_mult > 8) { af_set_error_msg("af_create: bad vae_ch_mult"); return AF_ERR_INVALID; }
     int rc = build_vae(b);
     if (rc) { af_destroy(h.release()); return rc; }
+    if (cfg->build_vae_encoder) {
+      if (cfg->vae_in_channels <= 0) { af_set_error_msg("af_create: vae_in_channels"); af_destroy(h.release()); return AF_ERR_INVALID; }
+      rc = build_vae_encoder(b);
+      if (rc) { af_destroy(h.release()); return rc; }
+    }
   }
   if (b.rc) { af_destroy(h.release()); return b.rc; }
   HIP_CHECK_RET(hipDeviceSynchronize());
@@ -1224,7 +1338,8 @@ int af_vae_decode(af_handle* h, const float* z_dev, float scale_factor, float* i
   if (!h || !z_dev || (!img_dev && !u8_dev)) { af_set_error_msg("af_vae_decode: null argument"); return AF_ERR_INVALID; }
   if (!h->cfg.build_vae) { af_set_error_msg("af_vae_decode: handle has no VAE"); return AF_ERR_STATE; }
   HIP_CHECK_RET(hipSetDevice(h->device));
-  AF_TRY(check_loaded(h, "first_stage_model."));
+  AF_TRY(check_loaded(h, "first_stage_model.decoder."));
+  AF_TRY(check_loaded(h, "first_stage_model.post_quant_conv."));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   h->arena.dry = true; h->arena.peak = 0;
   int rc = vae_decode_impl(h, s, z_dev, scale_factor, img_dev, u8_dev, B, H, W);
@@ -1232,6 +1347,29 @@ int af_vae_decode(af_handle* h, const float* z_dev, float scale_factor, float* i
   if (rc) return rc;
   if (h->arena.peak > h->arena.cap) { HIP_CHECK_RET(hipStreamSynchronize(s)); AF_TRY(ensure_arena(h, h->arena.peak)); }
   return vae_decode_impl(h, s, z_dev, scale_factor, img_dev, u8_dev, B, H, W);
+}
+
+int af_vae_encode(af_handle* h, const float* x_dev, float* moments_dev, int B, int H, int W, void* stream) {
+  if (!h || !x_dev || !moments_dev || B <= 0) { af_set_error_msg("af_vae_encode: bad argument"); return AF_ERR_INVALID; }
+  if (!h->cfg.build_vae || !h->cfg.build_vae_encoder) { af_set_error_msg("af_vae_encode: handle has no VAE encoder"); return AF_ERR_STATE; }
+  const int f = 1 << (h->cfg.n_vae_ch_mult - 1);
+  if (H % f != 0 || W % f != 0) { af_set_error_msg("af_vae_encode: H, W must be multiples of %d", f); return AF_ERR_INVALID; }
+  HIP_CHECK_RET(hipSetDevice(h->device));
+  AF_TRY(check_loaded(h, "first_stage_model.encoder."));
+  AF_TRY(check_loaded(h, "first_stage_model.quant_conv."));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  h->arena.dry = true; h->arena.peak = 0;
+  int rc = vae_encode_impl(h, s, x_dev, moments_dev, B, H, W);
+  h->arena.dry = false;
+  if (rc) return rc;
+  if (h->arena.peak > h->arena.cap) { HIP_CHECK_RET(hipStreamSynchronize(s)); AF_TRY(ensure_arena(h, h->arena.peak)); }
+  return vae_encode_impl(h, s, x_dev, moments_dev, B, H, W);
+}
+
+int af_posterior_sample(const float* moments_dev, const float* noise_dev, float scale, float* z_dev, int B, int C,
+                        int HW, void* stream) {
+  if (!moments_dev || !z_dev || B <= 0 || C <= 0 || HW <= 0) { af_set_error_msg("af_posterior_sample: bad argument"); return AF_ERR_INVALID; }
+  return af_launch_posterior_sample(moments_dev, noise_dev, scale, z_dev, B, C, (long)HW, reinterpret_cast<hipStream_t>(stream));
 }
 
 int af_to_uint8(const float* img_dev, uint8_t* u8_dev, int B, int H, int W, void* stream) {

@@ -64,6 +64,9 @@ class Engine:
             vm = list(vae["ch_mult"])
             cfg.n_vae_ch_mult = len(vm)
             _fill(cfg.vae_ch_mult, vm)
+            if vae.get("encoder", False):
+                cfg.build_vae_encoder = 1
+                cfg.vae_in_channels = vae.get("in_channels", 3)
         self.unet_cfg, self.vae_cfg = unet, vae
         torch.cuda.init()
         check(self._lib.af_create(device, C.byref(cfg), C.byref(self._h)), "af_create")
@@ -149,6 +152,25 @@ class Engine:
         if want_float and want_uint8:
             return img, u8
         return u8 if want_uint8 else img
+
+    def vae_encode(self, x: torch.Tensor) -> torch.Tensor:
+        """Encoder + quant_conv: x [B,3,H,W] -> posterior parameters [B, 2*embed_dim, H/f, W/f] (mean | logvar)."""
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        f = 2 ** (len(self.vae_cfg["ch_mult"]) - 1)
+        ed = self.vae_cfg.get("embed_dim", self.vae_cfg["z_channels"])
+        mom = torch.empty(B, 2 * ed, H // f, W // f, device=x.device, dtype=torch.float32)
+        check(self._lib.af_vae_encode(self._h, ptr(x), ptr(mom), B, H, W, stream_ptr()), "af_vae_encode")
+        return mom
+
+    def posterior_sample(self, moments: torch.Tensor, noise: Optional[torch.Tensor], scale: float = 1.0) -> torch.Tensor:
+        moments = moments.contiguous().float()
+        B, C2, H, W = moments.shape
+        z = torch.empty(B, C2 // 2, H, W, device=moments.device, dtype=torch.float32)
+        nz = None if noise is None else noise.contiguous().float()
+        check(self._lib.af_posterior_sample(ptr(moments), ptr(nz), float(scale), ptr(z), B, C2 // 2, H * W, stream_ptr()),
+              "af_posterior_sample")
+        return z
 
     def arena_bytes(self) -> int:
         return int(self._lib.af_arena_bytes(self._h))

@@ -155,3 +155,39 @@ def vae_decoder_param_shapes(*, ch, out_ch, ch_mult, num_res_blocks, z_channels,
     wb("norm_out", (block_in,))
     wb("conv_out", (out_ch, block_in, 3, 3))
     return shapes
+
+
+def vae_encoder_param_shapes(*, ch, ch_mult, num_res_blocks, z_channels, in_channels=3, **_unused) -> Dict[str, Shape]:
+    """Keys relative to `first_stage_model.encoder.` (Encoder.__init__, model.py:408-470)."""
+    shapes: Dict[str, Shape] = {}
+
+    def wb(name, w_shape):
+        shapes[name + ".weight"] = tuple(w_shape)
+        shapes[name + ".bias"] = (w_shape[0],)
+
+    def res(p, cin, cout):
+        wb(p + ".norm1", (cin,))
+        wb(p + ".conv1", (cout, cin, 3, 3))
+        wb(p + ".norm2", (cout,))
+        wb(p + ".conv2", (cout, cout, 3, 3))
+        if cin != cout:
+            wb(p + ".nin_shortcut", (cout, cin, 1, 1))
+
+    nres = len(ch_mult)
+    wb("conv_in", (ch, in_channels, 3, 3))
+    block_in = ch
+    for lvl in range(nres):
+        block_out = ch * ch_mult[lvl]
+        for i in range(num_res_blocks):
+            res(f"down.{lvl}.block.{i}", block_in, block_out)
+            block_in = block_out
+        if lvl != nres - 1:
+            wb(f"down.{lvl}.downsample.conv", (block_in, block_in, 3, 3))
+    res("mid.block_1", block_in, block_in)
+    wb("mid.attn_1.norm", (block_in,))
+    for n in ("q", "k", "v", "proj_out"):
+        wb("mid.attn_1." + n, (block_in, block_in, 1, 1))
+    res("mid.block_2", block_in, block_in)
+    wb("norm_out", (block_in,))
+    wb("conv_out", (2 * z_channels, block_in, 3, 3))
+    return shapes

@@ -1,6 +1,6 @@
 """Drop-in for ldm.models.autoencoder.AutoencoderKL (reference autoencoder.py:285-423),
-decode side: post_quant_conv + Decoder (model.py:502-608) as one af_vae_decode call.
-The encoder (init-image path) is a 'next' row and raises.
+decode side: post_quant_conv + Decoder (model.py:502-608) as one af_vae_decode call; encode side (init-image path,
+SURVEY.md §8f-3): Encoder (model.py:408-499) + quant_conv as one af_vae_encode call returning the posterior.
 """
 from __future__ import annotations
 
@@ -8,6 +8,34 @@ import torch
 
 from adaface_amd import layout
 from adaface_amd.ldm._hipmodule import HipModule, build_param_tree
+
+
+class DiagonalGaussianDistribution:
+    """ldm/modules/distributions/distributions.py:24-62 (the members the inference path reads).  `sample()` draws its
+    noise with torch.randn on the parameters' device, like the reference; the arithmetic is af_posterior_sample."""
+
+    def __init__(self, parameters, deterministic=False, engine=None):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.deterministic = deterministic
+        self._engine = engine
+
+    @property
+    def std(self):
+        return torch.zeros_like(self.mean) if self.deterministic else torch.exp(0.5 * self.logvar)
+
+    @property
+    def var(self):
+        return torch.zeros_like(self.mean) if self.deterministic else torch.exp(self.logvar)
+
+    def sample(self, noise=None, scale: float = 1.0):
+        if noise is None and not self.deterministic:
+            noise = torch.randn(self.mean.shape, device=self.parameters.device)
+        return self._engine.posterior_sample(self.parameters, None if self.deterministic else noise, scale)
+
+    def mode(self):
+        return self.mean
 
 
 class AutoencoderKL(HipModule):
@@ -30,6 +58,11 @@ class AutoencoderKL(HipModule):
             z_channels=dd["z_channels"]).items()}
         dec["post_quant_conv.weight"] = (dd["z_channels"], embed_dim, 1, 1)
         dec["post_quant_conv.bias"] = (dd["z_channels"],)
+        dec.update({"encoder." + k: v for k, v in layout.vae_encoder_param_shapes(
+            ch=dd["ch"], ch_mult=tuple(dd["ch_mult"]), num_res_blocks=dd["num_res_blocks"], z_channels=dd["z_channels"],
+            in_channels=dd.get("in_channels", 3)).items()})
+        dec["quant_conv.weight"] = (2 * embed_dim, 2 * dd["z_channels"], 1, 1)
+        dec["quant_conv.bias"] = (2 * embed_dim,)
         build_param_tree(self, dec)
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
@@ -38,7 +71,7 @@ class AutoencoderKL(HipModule):
         dd = self.ddconfig
         return {"vae": dict(ch=dd["ch"], out_ch=dd["out_ch"], ch_mult=tuple(dd["ch_mult"]),
                             num_res_blocks=dd["num_res_blocks"], z_channels=dd["z_channels"],
-                            embed_dim=self.embed_dim)}
+                            embed_dim=self.embed_dim, encoder=True, in_channels=dd.get("in_channels", 3))}
 
     def init_from_ckpt(self, path, ignore_keys=()):
         sd = torch.load(path, map_location="cpu", weights_only=True)
@@ -54,8 +87,13 @@ class AutoencoderKL(HipModule):
             return eng.vae_decode(z, scale_factor=scale_factor, want_uint8=True, want_float=False)
         return eng.vae_decode(z, scale_factor=scale_factor)
 
+    @torch.no_grad()
     def encode(self, x, mask=None):
-        raise NotImplementedError("AutoencoderKL.encode (init-image path) is a 'next' row (SURVEY.md §8f-3)")
+        """autoencoder.py:324-328: Encoder + quant_conv -> DiagonalGaussianDistribution."""
+        if mask is not None:
+            raise NotImplementedError("AutoencoderKL.encode: attention masks are a training-time option")
+        eng = self.engine(x.device)
+        return DiagonalGaussianDistribution(eng.vae_encode(x), engine=eng)
 
     def forward(self, input, sample_posterior=True, mask=None):
         raise NotImplementedError("autoencoder training forward is out of scope")

@@ -177,8 +177,20 @@ class LatentDiffusion(DDPM):
         """decode + clamp((x+1)/2,0,1)*255 -> uint8 HWC (stable_txt2img.py:713-715,764-765) in one pass."""
         return self.first_stage_model.decode(z, scale_factor=self.scale_factor, return_uint8=True)
 
+    @torch.no_grad()
     def encode_first_stage(self, x, mask=None):
-        raise NotImplementedError("VAE encoder / init-image path is a 'next' row (SURVEY.md §8f-3)")
+        """ddpm.py:1372-1410 (the non-patched branch): first_stage_model.encode -> posterior."""
+        return self.first_stage_model.encode(x, mask)
+
+    @torch.no_grad()
+    def get_first_stage_encoding(self, encoder_posterior):
+        """ddpm.py:947-954: sample the posterior (a tensor passes through) and apply scale_factor."""
+        from adaface_amd.ldm.models.autoencoder import DiagonalGaussianDistribution
+        if isinstance(encoder_posterior, DiagonalGaussianDistribution):
+            return encoder_posterior.sample(scale=self.scale_factor)
+        if isinstance(encoder_posterior, torch.Tensor):
+            return self.scale_factor * encoder_posterior
+        raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
 
     def set_compute_dtype(self, dtype: str):
         self.model.diffusion_model.set_compute_dtype(dtype)

@@ -48,6 +48,9 @@ typedef struct af_config {
   int build_vae;
   int vae_ch, vae_out_ch, vae_num_res_blocks, vae_z_channels, vae_embed_dim;
   int n_vae_ch_mult, vae_ch_mult[8];
+  /* VAE encoder (init-image path: Encoder model.py:408-499 + quant_conv autoencoder.py:304); needs build_vae */
+  int build_vae_encoder;
+  int vae_in_channels;            /* 3 */
 } af_config;
 
 const char* af_last_error(void);
@@ -98,6 +101,15 @@ int af_vae_decode(af_handle* h, const float* z_dev, float scale_factor, float* i
                   int W, void* stream);
 
 /* clamp((x+1)/2,0,1)*255 -> uint8 HWC from an fp32 NCHW image [B,3,H,W]. */
+/* AutoencoderKL.encode up to the posterior parameters (autoencoder.py:324-326): Encoder.forward + quant_conv.
+ * x_dev NCHW [B, in_channels, H, W] fp32 (H, W multiples of 2^(levels-1)); moments_dev NCHW
+ * [B, 2*embed_dim, H/f, W/f] fp32 = (mean | logvar), f = 2^(levels-1). */
+int af_vae_encode(af_handle* h, const float* x_dev, float* moments_dev, int B, int H, int W, void* stream);
+/* DiagonalGaussianDistribution.sample / .mode (distributions.py:24-37,61-62) + get_first_stage_encoding
+ * (ddpm.py:947-954): z = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise); noise_dev null = mode().
+ * moments [B, 2C, HW], noise / z [B, C, HW], all NCHW fp32. */
+int af_posterior_sample(const float* moments_dev, const float* noise_dev, float scale, float* z_dev, int B, int C,
+                        int HW, void* stream);
 int af_to_uint8(const float* img_dev, uint8_t* u8_dev, int B, int H, int W, void* stream);
 
 /* bytes of the activation arena currently reserved by the handle (diagnostics) */

@@ -211,6 +211,48 @@ def vae_param_shapes(cfg: VAEConfig, prefix: str = VAE_PREFIX) -> Dict[str, Tupl
     return out
 
 
+def vae_encoder_param_shapes(cfg: VAEConfig, prefix: str = VAE_PREFIX, in_channels: int = 3) -> Dict[str, Tuple[int, ...]]:
+    """Encoder.__init__ (model.py:408-470) + quant_conv (autoencoder.py:304): the init-image side of the VAE."""
+    out: Dict[str, Tuple[int, ...]] = {}
+
+    def conv(name, cin, cout, k):
+        out[name + ".weight"] = (cout, cin, k, k)
+        out[name + ".bias"] = (cout,)
+
+    def norm(name, c):
+        out[name + ".weight"] = (c,)
+        out[name + ".bias"] = (c,)
+
+    def res(p, cin, cout):
+        norm(p + ".norm1", cin)
+        conv(p + ".conv1", cin, cout, 3)
+        norm(p + ".norm2", cout)
+        conv(p + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(p + ".nin_shortcut", cin, cout, 1)
+
+    e = prefix + "encoder."
+    conv(e + "conv_in", in_channels, cfg.ch, 3)
+    nres = len(cfg.ch_mult)
+    block_in = cfg.ch
+    for lvl in range(nres):
+        block_out = cfg.ch * cfg.ch_mult[lvl]
+        for i in range(cfg.num_res_blocks):
+            res(f"{e}down.{lvl}.block.{i}", block_in, block_out)
+            block_in = block_out
+        if lvl != nres - 1:
+            conv(f"{e}down.{lvl}.downsample.conv", block_in, block_in, 3)
+    res(e + "mid.block_1", block_in, block_in)
+    norm(e + "mid.attn_1.norm", block_in)
+    for n in ("q", "k", "v", "proj_out"):
+        conv(e + "mid.attn_1." + n, block_in, block_in, 1)
+    res(e + "mid.block_2", block_in, block_in)
+    norm(e + "norm_out", block_in)
+    conv(e + "conv_out", block_in, 2 * cfg.z_channels, 3)
+    conv(prefix + "quant_conv", 2 * cfg.z_channels, 2 * cfg.embed_dim, 1)
+    return out
+
+
 def synth_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int) -> SD:
     """Seeded synthetic weights (no checkpoint exists offline).  Weights ~ N(0, 1/fan_in)·gain,
     norm scales ~ 1 + 0.1 N, biases / shifts ~ 0.05 N.  The reference's zero-initialised tensors
@@ -447,6 +489,35 @@ def vae_decode(sd: SD, cfg: VAEConfig, z: Tensor, prefix: str = VAE_PREFIX, scal
         if lvl != 0:
             h = _conv(sd, f"{d}up.{lvl}.upsample.conv", F.interpolate(h, scale_factor=2.0, mode="nearest"))
     return _conv(sd, d + "conv_out", _swish(_gn(sd, d + "norm_out", h, 1e-6)))
+
+
+def vae_encode_moments(sd: SD, cfg: VAEConfig, x: Tensor, prefix: str = VAE_PREFIX) -> Tensor:
+    """AutoencoderKL.encode up to the posterior parameters (autoencoder.py:324-328): Encoder.forward
+    (model.py:472-499; Downsample pads right/bottom by one and convolves with stride 2, pad 0: model.py:73-77)
+    then quant_conv.  Returns moments [B, 2*embed_dim, h, w] = (mean | logvar)."""
+    e = prefix + "encoder."
+    h = _conv(sd, e + "conv_in", x.float())
+    nres = len(cfg.ch_mult)
+    for lvl in range(nres):
+        for i in range(cfg.num_res_blocks):
+            h = vae_resblock(sd, f"{e}down.{lvl}.block.{i}", h)
+        if lvl != nres - 1:
+            h = _conv(sd, f"{e}down.{lvl}.downsample.conv", F.pad(h, (0, 1, 0, 1), mode="constant", value=0.0), stride=2, pad=0)
+    h = vae_resblock(sd, e + "mid.block_1", h)
+    h = vae_attn(sd, e + "mid.attn_1", h)
+    h = vae_resblock(sd, e + "mid.block_2", h)
+    h = _conv(sd, e + "conv_out", _swish(_gn(sd, e + "norm_out", h, 1e-6)))
+    return _conv(sd, prefix + "quant_conv", h, pad=0)
+
+
+def posterior_sample(moments: Tensor, noise: Optional[Tensor], scale_factor: float) -> Tensor:
+    """DiagonalGaussianDistribution (distributions.py:24-37) + get_first_stage_encoding (ddpm.py:947-954):
+    mean, logvar = chunk(moments, 2); logvar clamped to [-30, 20]; z = (mean + exp(0.5 logvar) * noise) * scale_factor
+    (noise None = mode())."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    z = mean if noise is None else mean + torch.exp(0.5 * logvar) * noise
+    return scale_factor * z
 
 
 def to_uint8_hwc(img: Tensor) -> np.ndarray:

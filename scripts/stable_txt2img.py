@@ -3,7 +3,7 @@
 
 Keeps the reference's flag names for everything that reaches the denoising path
 (stable_txt2img.py:38-310): --config --ckpt --n_samples --n_repeat --ddim_steps --ddim_eta --scale --H --W --C --f
---seed --outdir --skip_save --fixed_code --gpu --bs.  Text conditioning is the one difference: the CLIP tower /
+--seed --outdir --skip_save --fixed_code --gpu --bs --plms --init_img_paths --init_img_weight.  Text conditioning is the one difference: the CLIP tower /
 EmbeddingManager are out of scope offline, so prompts are given as pre-computed embeddings
 (--prompt_emb file.pt/.npy with a [B*16,77,768] or [77,768] tensor) or --synthetic.
 
@@ -44,10 +44,23 @@ def parse_args():
     ap.add_argument("--C", type=int, default=4)
     ap.add_argument("--f", type=int, default=8)
     ap.add_argument("--scale", type=float, nargs="+", default=[10.0, 4.0], help="guidance scale, or max min for annealing")
+    ap.add_argument("--init_img_paths", type=str, nargs="+", default=None,
+                    help="initial image(s): encoded by the VAE encoder, averaged, blended with noise into the start code")
+    ap.add_argument("--init_img_weight", type=float, default=0.1, help="w: start = w*enc(img) + (1-w)*noise")
+    ap.add_argument("--plms", action="store_true", help="PLMS sampler instead of DDIM (scalar --scale)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--gpu", type=int, default=None)
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     return ap.parse_args()
+
+
+def load_img(path, h, w):
+    """stable_txt2img.py:318-327: RGB, resized to multiples of 32, [-1, 1], NCHW."""
+    from PIL import Image
+    image = Image.open(path).convert("RGB")
+    w, h = (x - x % 32 for x in (w, h))
+    image = np.array(image.resize((w, h), resample=Image.LANCZOS)).astype(np.float32) / 255.0
+    return 2.0 * torch.from_numpy(image[None].transpose(0, 3, 1, 2)) - 1.0
 
 
 def load_emb(path, n, device):
@@ -109,11 +122,27 @@ def main():
         raise SystemExit("give --prompt_emb (pre-computed CLIP/AdaFace embedding) or --synthetic")
     c = model.get_learned_conditioning(shard_batch(c_all, rank, world, per_sample=16).to(device))
     uc = model.get_learned_conditioning(shard_batch(uc_all, rank, world, per_sample=16).to(device))
-    sampler = DDIMSampler(model)
+    if opt.plms:
+        from ldm.models.diffusion.plms import PLMSSampler
+        sampler = PLMSSampler(model)
+    else:
+        sampler = DDIMSampler(model)
     shape = [opt.C, opt.H // opt.f, opt.W // opt.f]
     gs = opt.scale if len(opt.scale) > 1 else opt.scale[0]
     gen = torch.Generator().manual_seed(opt.seed)  # host RNG: the start code does not depend on the world size
     start_code = torch.randn([B] + shape, generator=gen) if opt.fixed_code else None
+    if opt.init_img_paths:
+        # stable_txt2img.py:594-625: encode each init image, average (divide by sqrt(N)), blend with noise
+        avg = torch.zeros([B] + shape)
+        for path in opt.init_img_paths:
+            img = load_img(path, opt.H, opt.W).repeat(b, 1, 1, 1).to(device)
+            enc = model.get_first_stage_encoding(model.encode_first_stage(img))   # this rank's samples
+            avg[lo:hi] += enc.cpu()
+        if world > 1:
+            dist.all_reduce(avg_dev := avg.to(device))
+            avg = avg_dev.cpu()
+        avg /= np.sqrt(len(opt.init_img_paths))
+        start_code = avg * opt.init_img_weight + torch.randn([B] + shape, generator=gen) * (1.0 - opt.init_img_weight)
     os.makedirs(opt.outdir, exist_ok=True)
     tic = time.time()
     count = 0
@@ -121,8 +150,13 @@ def main():
         for n in range(opt.n_repeat):
             x_T_all = start_code if start_code is not None else torch.randn([B] + shape, generator=gen)
             x_T = shard_batch(x_T_all, rank, world).to(device)
-            samples, _ = sampler.sample(S=opt.ddim_steps, conditioning=c, batch_size=b, shape=shape, verbose=False,
-                                        guidance_scale=gs, unconditional_conditioning=uc, eta=opt.ddim_eta, x_T=x_T)
+            if opt.plms:
+                samples, _ = sampler.sample(S=opt.ddim_steps, conditioning=c, batch_size=b, shape=shape, verbose=False,
+                                            unconditional_guidance_scale=opt.scale[0], unconditional_conditioning=uc,
+                                            eta=opt.ddim_eta, x_T=x_T)
+            else:
+                samples, _ = sampler.sample(S=opt.ddim_steps, conditioning=c, batch_size=b, shape=shape, verbose=False,
+                                            guidance_scale=gs, unconditional_conditioning=uc, eta=opt.ddim_eta, x_T=x_T)
             frames = gather_frames(model.decode_first_stage_uint8(samples), global_batch=B)
             if rank == 0 and not opt.skip_save:
                 from PIL import Image

@@ -193,6 +193,31 @@ def main():
     golden["vae_z"] = z.numpy()
     golden["vae_tiny_img"] = img.numpy()
 
+    # ---- tiny VAE encoder (init-image side: Encoder + quant_conv + DiagonalGaussianDistribution) ----
+    # own generator: the draws above and in the --full section must not move
+    from ldm.modules.diffusionmodules.model import Encoder
+    from ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+    g2 = torch.Generator().manual_seed(4321)
+    esd = O.synth_state_dict(O.vae_encoder_param_shapes(vcfg), seed=13)
+    enc = Encoder(ch=vcfg.ch, out_ch=vcfg.out_ch, ch_mult=tuple(vcfg.ch_mult), num_res_blocks=vcfg.num_res_blocks,
+                  attn_resolutions=[], dropout=0.0, in_channels=3, resolution=256, z_channels=vcfg.z_channels,
+                  double_z=True).eval()
+    load(enc, esd, O.VAE_PREFIX + "encoder.")
+    qc = torch.nn.Conv2d(2 * vcfg.z_channels, 2 * vcfg.embed_dim, 1)
+    qc.weight.data.copy_(esd[O.VAE_PREFIX + "quant_conv.weight"])
+    qc.bias.data.copy_(esd[O.VAE_PREFIX + "quant_conv.bias"])
+    ximg = torch.rand(2, 3, 64, 128, generator=g2) * 2.0 - 1.0    # non-square: latent 8 x 16 (mid attention over 128 positions)
+    moments = qc(enc(ximg))                                       # autoencoder.py:324-326
+    post = DiagonalGaussianDistribution(moments)
+    torch.manual_seed(5)
+    zs = post.sample()                                            # distributions.py:35-37
+    torch.manual_seed(5)
+    noise = torch.randn(post.mean.shape)
+    golden["vae_enc_x"] = ximg.numpy()
+    golden["vae_enc_moments"] = moments.numpy()
+    golden["vae_enc_noise"] = noise.numpy()
+    golden["vae_enc_z"] = (vcfg.scale_factor * zs).numpy()        # get_first_stage_encoding, ddpm.py:947-954
+
     np.savez_compressed(OUT / "golden_tiny.npz", **golden)
     print("wrote", OUT / "golden_tiny.npz", {k: v.shape for k, v in list(golden.items())[:6]}, "...")
 

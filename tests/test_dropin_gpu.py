@@ -23,6 +23,7 @@ def tiny_model(gpu):
     model = instantiate_from_config(tiny_config()["model"]).eval()
     sd = O.synth_state_dict(O.unet_param_shapes(O.TINY_UNET), seed=11)
     sd.update(O.synth_state_dict(O.vae_param_shapes(O.TINY_VAE), seed=12))
+    sd.update(O.synth_state_dict(O.vae_encoder_param_shapes(O.TINY_VAE), seed=13))
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected
     return model.to(gpu).set_compute_dtype("f32")
@@ -133,5 +134,35 @@ def test_out_of_scope_branches_raise(gpu, tiny_model):
         tiny_model.apply_model(x, t, (emb, prompts, bad))
     with pytest.raises(NotImplementedError):
         tiny_model.get_learned_conditioning(["a photo of a z"])
-    with pytest.raises(NotImplementedError):
-        tiny_model.encode_first_stage(torch.zeros(1, 3, 128, 128, device=gpu))
+
+
+def test_encode_first_stage_matches_reference(gpu, report, tiny_model):
+    """Init-image path (stable_txt2img.py:594-625): encode_first_stage -> posterior -> get_first_stage_encoding, vs the
+    reference's Encoder + quant_conv + DiagonalGaussianDistribution on the same image and the same noise."""
+    g = dict(np.load(GOLD / "golden_tiny.npz"))
+    x = torch.tensor(g["vae_enc_x"], device=gpu)
+    post = tiny_model.encode_first_stage(x)
+    ref = g["vae_enc_moments"]
+    err = np.abs(post.parameters.cpu().numpy() - ref).max() / np.abs(ref).max()
+    report("dropin encode_first_stage moments vs reference golden [f32]", err, float(np.abs(ref).max()), 2e-4)
+    assert err < 2e-4
+    assert torch.equal(post.mode(), post.parameters[:, :4])
+    z = post.sample(noise=torch.tensor(g["vae_enc_noise"], device=gpu), scale=tiny_model.scale_factor)
+    zr = g["vae_enc_z"]
+    errz = np.abs(z.cpu().numpy() - zr).max() / np.abs(zr).max()
+    report("dropin posterior sample * scale_factor vs reference [f32]", errz, float(np.abs(zr).max()), 2e-4)
+    assert errz < 2e-4
+    torch.manual_seed(3)
+    z1 = tiny_model.get_first_stage_encoding(post)
+    torch.manual_seed(3)
+    z2 = tiny_model.get_first_stage_encoding(tiny_model.encode_first_stage(x))
+    assert z1.shape == (2, 4, 8, 16) and torch.equal(z1, z2)
+    # img2img entry (ddim.py:299-312): stochastic_encode of the encoded image, then the decode loop runs
+    from ldm.models.diffusion.ddim import DDIMSampler
+    sampler = DDIMSampler(tiny_model)
+    sampler.make_schedule(ddim_num_steps=5, ddim_eta=0.0, verbose=False)
+    zt = sampler.stochastic_encode(z1[:1].contiguous(), torch.tensor([2], device=gpu))
+    assert torch.isfinite(zt).all()
+    from adaface_amd._lib import AfError
+    with pytest.raises(AfError):   # H not a multiple of 2^(levels-1)
+        tiny_model.first_stage_model.engine(gpu).vae_encode(torch.zeros(1, 3, 60, 64, device=gpu))

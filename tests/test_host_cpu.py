@@ -60,6 +60,7 @@ def test_dropin_state_dict_keys_match_reference_inventory():
     keys = {k: tuple(v.shape) for k, v in m.state_dict().items() if k.startswith(("model.", "first_stage_model."))}
     ref = dict(O.unet_param_shapes(O.TINY_UNET))
     ref.update(O.vae_param_shapes(O.TINY_VAE))
+    ref.update(O.vae_encoder_param_shapes(O.TINY_VAE))   # encoder.* + quant_conv (init-image side)
     assert keys == {k: tuple(v) for k, v in ref.items()}
     # SD-1.5 inventory without allocating 3.4 GB: through the layout module
     from adaface_amd import layout

@@ -135,3 +135,15 @@ def test_sd15_vae_matches_reference():
     scale = max(1.0, float(g["sd15_vae_img_stats"][2]))
     assert np.abs(crop - g["sd15_vae_img_crop"]).max() < 5e-5 * scale
     assert np.abs(img[:, :, ::8, ::8].numpy() - g["sd15_vae_img_sub8"]).max() < 5e-5 * scale
+
+
+def test_tiny_vae_encoder_matches_reference(tiny):
+    """Encoder + quant_conv moments and the posterior sample vs the reference's Encoder / DiagonalGaussianDistribution."""
+    cfg = O.TINY_VAE
+    sd = O.synth_state_dict(O.vae_encoder_param_shapes(cfg), seed=13)
+    mom = O.vae_encode_moments(sd, cfg, torch.tensor(tiny["vae_enc_x"]))
+    ref = tiny["vae_enc_moments"]
+    assert mom.shape == ref.shape
+    assert np.abs(mom.numpy() - ref).max() < 2e-5 * np.abs(ref).max()
+    z = O.posterior_sample(torch.tensor(ref), torch.tensor(tiny["vae_enc_noise"]), cfg.scale_factor)
+    assert np.abs(z.numpy() - tiny["vae_enc_z"]).max() < 1e-6 * np.abs(tiny["vae_enc_z"]).max()
