@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x, 
 // row in registers, so all 64 lanes are busy at C = 320 (the wave-per-row kernel above leaves 24 of 64 idle there and
 // fetches gamma / beta with 16 scalar loads per vector; here they sit in LDS and are read as 16-byte vectors).
 // One load instruction covers 64/RL rows x 128 contiguous bytes.  Same two-pass variance in fp32.
-#define LNG_MAXV 20
+#define LNG_MAXV 10
 template <typename T, int RL>
 __global__ __launch_bounds__(256) void layernorm_rowgroup_kernel(const T* __restrict__ x, int ldx, long rows, int Cn,
                                                                   const float* __restrict__ gamma,

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const bf16* __restrict__ X
                                                       unsigned long long* __restrict__ dbg) {
   constexpr int BM = 256, BK = 64;
   constexpr bool STAMP = (MODE & 32) != 0;
+  constexpr bool PERSIST = (MODE & 128) != 0;   // workgroups loop over output tiles; the DMA ring runs across tile boundaries
   constexpr int HN = BN / 2;          // columns per wave group
   constexpr int NI = HN / 16;         // 16-wide n tiles per wave
   constexpr int MI = 4;               // 16-high m tiles per wave (64 rows)
@@ -97,18 +98,21 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const bf16* __restrict__ X
   const int srow = lane >> 3;
   const unsigned lchunk = (unsigned)((lane & 7) ^ srow);  // XOR swizzle applied on the SOURCE address
   unsigned goff[NPMAX];
-  static_for<0, NPMAX>([&](auto qc) {
-    constexpr int q = decltype(qc)::value;
-    unsigned v = 0xFFFFFFFFu;
-    if (g == 0) {
-      if (q < NP0) { const int m = m0 + (wq + 4 * q) * 8 + srow; if (m < M) v = (unsigned)m * (unsigned)K * 2u + lchunk * 16u; }
-    } else if (q < XP1 / 4) {
-      const int m = m0 + (XP0 + wq + 4 * q) * 8 + srow; if (m < M) v = (unsigned)m * (unsigned)K * 2u + lchunk * 16u;
-    } else if (q < NP1) {
-      v = (unsigned)(n0 + (wq + 4 * (q - XP1 / 4)) * 8 + srow) * (unsigned)K * 2u + lchunk * 16u;
-    }
-    goff[q] = v;
-  });
+  auto compute_goff = [&](int m0_, int n0_) {
+    static_for<0, NPMAX>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      unsigned v = 0xFFFFFFFFu;
+      if (g == 0) {
+        if (q < NP0) { const int m = m0_ + (wq + 4 * q) * 8 + srow; if (m < M) v = (unsigned)m * (unsigned)K * 2u + lchunk * 16u; }
+      } else if (q < XP1 / 4) {
+        const int m = m0_ + (XP0 + wq + 4 * q) * 8 + srow; if (m < M) v = (unsigned)m * (unsigned)K * 2u + lchunk * 16u;
+      } else if (q < NP1) {
+        v = (unsigned)(n0_ + (wq + 4 * (q - XP1 / 4)) * 8 + srow) * (unsigned)K * 2u + lchunk * 16u;
+      }
+      goff[q] = v;
+    });
+  };
+  compute_goff(m0, n0);
   auto piece = [&](auto qc, int slot_off, unsigned kb) {
     constexpr int q = decltype(qc)::value;
     if (g == 0) {
@@ -200,6 +204,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const bf16* __restrict__ X
     });
   };
 
+  // ---- epilogue: acc[i][j][r] -> C[m0 + wq*64 + j*16 + (lane&15)][n0 + g*HN + i*16 + 4*(lane>>4) + r] ----
+  auto store_tile = [&](int m0_, int n0_) {
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int m = m0_ + wq * 64 + j * 16 + (lane & 15);
+      if (m >= M) continue;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int n = n0_ + g * HN + i * 16 + 4 * (lane >> 4);
+        union { bf16 h[4]; uint2 u; } pk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pk.h[r] = (bf16)acc[i][j][r];
+        *reinterpret_cast<uint2*>(C + (size_t)m * N + n) = pk.u;
+      }
+    }
+  };
   constexpr bool LAG = (MODE & 64) != 0;
   std::integral_constant<int, 0> U0; std::integral_constant<int, 1> U1;
   auto stamp = [&]() -> unsigned long long {
@@ -212,6 +232,88 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const bf16* __restrict__ X
     return v;
   };
   unsigned long long s_load = 0, s_b1 = 0, s_comp = 0, s_vm = 0, s_b2 = 0, rt0 = 0, tbeg = 0, ta = 0;
+  if constexpr (PERSIST) {
+    const int ntiles = ntm * ntn;
+    const int nloc = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
+    const int G = nloc * KT;                                                             // its K-tile stream
+    auto tile_of = [&](int i, int& m0_, int& n0_) {
+      int tm_, tn_;
+      tile_coords((int)blockIdx.x + i * (int)gridDim.x, ntiles, ntm, ntn, gm, tm_, tn_);
+      m0_ = tm_ * BM; n0_ = tn_ * BN;
+    };
+    int st_i = 0, st_kt = 0;          // staging cursor (runs 1-2 K tiles ahead of the compute cursor)
+    { int a_, b_; tile_of(0, a_, b_); compute_goff(a_, b_); }
+    auto stage_next = [&](int slot_off) {
+      stage(slot_off, st_kt);
+      if (++st_kt == KT) {
+        st_kt = 0;
+        if (++st_i < nloc) { int a_, b_; tile_of(st_i, a_, b_); compute_goff(a_, b_); }
+      }
+    };
+    int cm0, cn0, c_i = 0, c_kt = 0;  // compute cursor
+    tile_of(0, cm0, cn0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf[i][1] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < MI; ++j) xf[j][1] = u32x4{0u, 0u, 0u, 0u};
+    stage_next(0);
+    if (g == 1) { if (G > 1) { stage_next(SLOT); wait_keep1(); } else wait_vm<0>(); }
+    __builtin_amdgcn_s_barrier();
+    if (g == 1) __builtin_amdgcn_s_barrier();
+    int rd = 0, w0 = SLOT, w1 = 2 * SLOT;
+    unsigned long long s_epi = 0;
+    if constexpr (STAMP) rt0 = __builtin_amdgcn_s_memrealtime();
+    tbeg = stamp(); ta = tbeg;
+    for (int t = 0; t < G; ++t) {
+      if (g == 0) { if (t + 1 < G) { stage_next(w0); wait_keep1(); } else wait_vm<0>(); }
+      else { if (t + 2 < G) stage_next(w1); }
+      const unsigned long long tb = stamp();
+      __builtin_amdgcn_s_barrier();
+      const unsigned long long tc = stamp();
+      __builtin_amdgcn_s_setprio(1);
+      half(rd, U0, U1);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lgkm0();
+      __builtin_amdgcn_sched_barrier(0);
+      half(rd, U1, U0);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lgkm0();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
+      const unsigned long long td = stamp();
+      if (++c_kt == KT) {
+        // tile finished: the trailing half tile, the output, then a clean accumulator / "unit -1" for the next tile
+        mfma_unit(U1);
+        store_tile(cm0, cn0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf[i][1] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < MI; ++j) xf[j][1] = u32x4{0u, 0u, 0u, 0u};
+        c_kt = 0;
+        if (++c_i < nloc) tile_of(c_i, cm0, cn0);
+      }
+      const unsigned long long tx = stamp();
+      if (g == 1) { if (t + 2 < G) wait_keep1(); else wait_vm<0>(); }
+      const unsigned long long te = stamp();
+      __builtin_amdgcn_s_barrier();
+      const unsigned long long tf = stamp();
+      if constexpr (STAMP) { s_load += tb - ta; s_b1 += tc - tb; s_comp += td - tc; s_epi += tx - td; s_vm += te - tx; s_b2 += tf - te; ta = tf; }
+      const int tmp = rd; rd = w0; w0 = w1; w1 = tmp;
+    }
+    if constexpr (STAMP) {
+      const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+      if (blockIdx.x == 0 && lane == 0) {
+        unsigned long long* d = dbg + wid * 8;
+        d[0] = s_load; d[1] = s_b1; d[2] = s_comp; d[3] = s_vm; d[4] = s_b2; d[5] = ta - tbeg; d[6] = rt1 - rt0; d[7] = G;
+        dbg[64 + wid] = s_epi;
+      }
+    }
+    if (g == 0) __builtin_amdgcn_s_barrier();
+  } else
   if constexpr (LAG) {
     // ---- "lag" pipeline: the DMA segment only issues DMA; the compute segment reads the K-halves (units) of tile t
     // while the MFMAs run half a tile behind: [read unit 2t | MFMA unit 2t-1] [read unit 2t+1 | MFMA unit 2t].
@@ -305,7 +407,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const bf16* __restrict__ X
   }
   if (g == 0) __builtin_amdgcn_s_barrier();
   }
-  if constexpr (STAMP) {
+  if constexpr (STAMP && !PERSIST) {
     const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
     if (blockIdx.x == 0 && lane == 0) {
       unsigned long long* d = dbg + wid * 8;
@@ -313,20 +415,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const bf16* __restrict__ X
     }
   }
 
-  // ---- epilogue: acc[i][j][r] -> C[m0 + wq*64 + j*16 + (lane&15)][n0 + g*HN + i*16 + 4*(lane>>4) + r] ----
-#pragma unroll
-  for (int j = 0; j < MI; ++j) {
-    const int m = m0 + wq * 64 + j * 16 + (lane & 15);
-    if (m >= M) continue;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int n = n0 + g * HN + i * 16 + 4 * (lane >> 4);
-      union { bf16 h[4]; uint2 u; } pk;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pk.h[r] = (bf16)acc[i][j][r];
-      *reinterpret_cast<uint2*>(C + (size_t)m * N + n) = pk.u;
-    }
-  }
+  if constexpr (!PERSIST) store_tile(m0, n0);
 }
 
 static uint16_t f2bf(float f) {
@@ -339,12 +428,17 @@ static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(
 static unsigned long long* g_dbg = nullptr;
 template <int BN, int MODE>
 static double run(const char* name, const bf16* dX, const bf16* dW, bf16* dC, int M, int N, int K, int gm, int iters) {
-  if (!g_dbg) CK(hipMalloc(&g_dbg, 64 * 8));
+  if (!g_dbg) CK(hipMalloc(&g_dbg, 128 * 8));
   constexpr int SLOT = (256 + BN) * 128;
   const int lds = 3 * SLOT;
   CK(hipFuncSetAttribute((const void*)gemm_pp_kernel<BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   const int ntm = (M + 255) / 256, ntn = N / BN;
-  dim3 grid(ntm * ntn), block(512);
+  int nblk = ntm * ntn;
+  if (MODE & 128) {   // persistent: equal share of tiles per workgroup, at most one workgroup per CU
+    const int rounds = (nblk + 255) / 256;
+    nblk = (nblk + rounds - 1) / rounds;
+  }
+  dim3 grid(nblk), block(512);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_pp_kernel<BN, MODE>), grid, block, lds, 0, dX, dW, dC, M, N, K, gm, g_dbg);
   CK(hipDeviceSynchronize());
@@ -356,13 +450,15 @@ static double run(const char* name, const bf16* dX, const bf16* dW, bf16* dC, in
   const double tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
   printf("%-28s M=%6d N=%5d K=%5d grid=%4d  %8.1f us  %7.1f TF/s\n", name, M, N, K, ntm * ntn, us, tf);
   if (MODE & 32) {
-    unsigned long long h[64];
+    unsigned long long h[128];
     CK(hipMemcpy(h, g_dbg, sizeof(h), hipMemcpyDeviceToHost));
     for (int w : {0, 4}) {
       const unsigned long long* d = h + w * 8;
       const double kt = (double)d[7];
       printf("    wave %d per K-tile: load %.0f  bar1 %.0f  mfma %.0f  vmwait %.0f  bar2 %.0f  | total %.0f cyc/tile, clock %.0f MHz\n", w,
              d[0] / kt, d[1] / kt, d[2] / kt, d[3] / kt, d[4] / kt, d[5] / kt, (double)d[5] / (double)d[6] * 100.0);
+      if (MODE & 128) printf("      epilogue (store + reset) %.0f cyc per K-tile = %.0f per output tile (K-tiles per output tile %d)\n",
+                             h[64 + w] / kt, (double)h[64 + w] / kt * (K / 64), K / 64);
     }
   }
   return tf;
@@ -370,8 +466,7 @@ static double run(const char* name, const bf16* dX, const bf16* dW, bf16* dC, in
 
 int main(int argc, char** argv) {
   struct Shape { int M, N, K; };
-  std::vector<Shape> shapes = {{16384, 640, 5760}, {65536, 320, 2880}, {4096, 1280, 11520}, {16384, 640, 2560},
-                               {65536, 320, 1280}, {65536, 2560, 320}, {4096, 1280, 5120}, {16384, 8000, 8192}};
+  std::vector<Shape> shapes = {{65536, 320, 2880}, {65536, 960, 320}, {65536, 2560, 320}, {16384, 5120, 640}};
   size_t maxX = 0, maxW = 0, maxC = 0;
   for (auto& s : shapes) { maxX = std::max(maxX, (size_t)s.M * s.K); maxW = std::max(maxW, (size_t)s.N * s.K); maxC = std::max(maxC, (size_t)s.M * s.N); }
   std::vector<uint16_t> hX(maxX), hW(maxW), hC(maxC);
@@ -403,11 +498,8 @@ int main(int argc, char** argv) {
       }
       printf("    check: max scaled err %.3e, bad %d / 512\n", maxerr, bad);
     };
-    run<160, 2>("pp256x160 bal", dX, dW, dC, s.M, s.N, s.K, gm, 20); check();
-    run<160, 2 + 64>("pp256x160 bal LAG", dX, dW, dC, s.M, s.N, s.K, gm, 20); check();
-    run<160, 64>("pp256x160 LAG", dX, dW, dC, s.M, s.N, s.K, gm, 20); check();
-    run<160, 2 + 64 + 32>("pp256x160 bal LAG STAMP", dX, dW, dC, s.M, s.N, s.K, gm, 20);
-    run<160, 2 + 64 + 4 + 32>("pp256x160 bal LAG noDMA STAMP", dX, dW, dC, s.M, s.N, s.K, gm, 20);
+    run<160, 2 + 64 + 128>("pp256x160 bal LAG PERSIST", dX, dW, dC, s.M, s.N, s.K, gm, 20); check();
+    run<160, 2 + 64 + 128 + 32>("pp256x160 bal LAG PERSIST STAMP", dX, dW, dC, s.M, s.N, s.K, gm, 20);
   }
   return 0;
 }
