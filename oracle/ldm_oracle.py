@@ -353,9 +353,45 @@ def resblock(sd: SD, p: str, x: Tensor, emb: Tensor) -> Tensor:
     return x + h
 
 
-def cross_attention(sd: SD, p: str, x: Tensor, k_ctx: Optional[Tensor], v_ctx: Optional[Tensor], heads: int) -> Tensor:
-    """CrossAttention.forward (attention.py:172-243) without the conv-attn / mask branches:
-    q,k,v linears without bias, per-head softmax(q k^T dh^-0.5) v, to_out linear with bias."""
+def conv_attn_rows(sim: Tensor, q: Tensor, k: Tensor, subj_indices, infeat_size, ks: int, scale: float) -> Tensor:
+    """replace_rows_by_conv_attn (ldm/util.py:701-879) with conv_attn_mix_weight = 1 and shifted maps:
+    for every batch element that carries the subject, A[h](y,x) = scale / ks^1.5 * sum_{ky,kx,c} q[h][(y+ky-1, x+kx-1)][c]
+    * k[h][token(ky,kx)][c] (zero-padded q; the first ks^2 subject tokens are the kernel taps, row-major), and the
+    score column of subject token j = (jy, jx) is A shifted by (dy, dx) = (jy-1, jx-1) with zero fill:
+    col_j(y,x) = A(y-dy, x-dx).  sim [B,H,N,T], q [B,H,N,dh], k [B,H,T,dh]; subj_indices = (indices_B, indices_N)."""
+    if ks == 1:
+        return sim
+    assert ks == 3, "the inference path uses 3x3 (ks = 2 / 4 pad asymmetrically: util.py:749-758)"
+    idx_b, idx_n = (torch.as_tensor(t) for t in subj_indices)
+    uniq = torch.unique(idx_b)
+    M = idx_n.numel() // uniq.numel()
+    assert ks * ks <= M
+    Hh, Ww = infeat_size
+    B, H, N, dh = q.shape
+    out = sim.clone()
+    for bi, b in enumerate(uniq.tolist()):
+        toks = idx_n[bi * M: bi * M + ks * ks].tolist()
+        q4 = q[b].permute(0, 2, 1).reshape(1, H * dh, Hh, Ww)
+        w = k[b][:, toks, :].permute(0, 2, 1).reshape(H, dh, ks, ks)        # [H, dh, ky, kx]: taps row-major
+        A = F.conv2d(F.pad(q4, (1, 1, 1, 1)), w, groups=H)[0] * scale / ks ** 1.5   # [H, Hh, Ww]
+        j = 0
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                sh = torch.zeros_like(A)
+                ys, xs = slice(max(dy, 0), Hh + min(dy, 0)), slice(max(dx, 0), Ww + min(dx, 0))
+                yr, xr = slice(max(-dy, 0), Hh + min(-dy, 0)), slice(max(-dx, 0), Ww + min(-dx, 0))
+                sh[:, ys, xs] = A[:, yr, xr]                                   # sh(y,x) = A(y-dy, x-dx)
+                out[b, :, :, toks[j]] = sh.reshape(H, N)
+                j += 1
+    return out
+
+
+def cross_attention(sd: SD, p: str, x: Tensor, k_ctx: Optional[Tensor], v_ctx: Optional[Tensor], heads: int,
+                    conv_attn=None) -> Tensor:
+    """CrossAttention.forward (attention.py:172-243): q,k,v linears without bias, per-head softmax(q k^T dh^-0.5) v,
+    to_out linear with bias.  conv_attn = (subj_indices, infeat_size, ks) enables the subject-token row replacement
+    (:208-216) on cross-attention layers; the mask branch is a training-time option."""
+    context_provided = k_ctx is not None
     if k_ctx is None:
         k_ctx = v_ctx = x
     q, k, v = _lin(sd, p + ".to_q", x), _lin(sd, p + ".to_k", k_ctx), _lin(sd, p + ".to_v", v_ctx)
@@ -364,6 +400,8 @@ def cross_attention(sd: SD, p: str, x: Tensor, k_ctx: Optional[Tensor], v_ctx: O
     split = lambda t: t.reshape(B, -1, heads, dh).permute(0, 2, 1, 3)
     q, k, v = split(q), split(k), split(v)
     sim = torch.einsum("bhid,bhjd->bhij", q, k) * dh ** -0.5
+    if context_provided and conv_attn is not None and conv_attn[2] > 0:
+        sim = conv_attn_rows(sim, q, k, conv_attn[0], conv_attn[1], conv_attn[2], dh ** -0.5)
     out = torch.einsum("bhij,bhjd->bhid", sim.softmax(dim=-1), v)
     out = out.permute(0, 2, 1, 3).reshape(B, N, C)
     return _lin(sd, p + ".to_out.0", out)
@@ -379,7 +417,8 @@ def _ln(sd: SD, p: str, x: Tensor) -> Tensor:
     return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
 
 
-def spatial_transformer(sd: SD, p: str, x: Tensor, ctx: Optional[Tensor], heads: int, depth: int) -> Tensor:
+def spatial_transformer(sd: SD, p: str, x: Tensor, ctx: Optional[Tensor], heads: int, depth: int,
+                        conv_attn=None) -> Tensor:
     """SpatialTransformer.forward (attention.py:321-341) + BasicTransformerBlock._forward (:275-285):
     GN(eps 1e-6) -> 1x1 -> tokens -> [x+=attn1(LN x); x+=attn2(LN x, ctx); x+=ff(LN x)] -> 1x1 -> + input."""
     B, C, H, W = x.shape
@@ -388,7 +427,8 @@ def spatial_transformer(sd: SD, p: str, x: Tensor, ctx: Optional[Tensor], heads:
     for d in range(depth):
         t = f"{p}.transformer_blocks.{d}"
         h = cross_attention(sd, t + ".attn1", _ln(sd, t + ".norm1", h), None, None, heads) + h
-        h = h + cross_attention(sd, t + ".attn2", _ln(sd, t + ".norm2", h), ctx, ctx, heads)
+        ca = None if conv_attn is None else (conv_attn[0], (H, W), conv_attn[1])   # infeat_size: attention.py:330
+        h = h + cross_attention(sd, t + ".attn2", _ln(sd, t + ".norm2", h), ctx, ctx, heads, conv_attn=ca)
         h = feed_forward(sd, t + ".ff", _ln(sd, t + ".norm3", h)) + h
     h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
     return _conv(sd, p + ".proj_out", h, pad=0) + x
@@ -396,7 +436,7 @@ def spatial_transformer(sd: SD, p: str, x: Tensor, ctx: Optional[Tensor], heads:
 
 def unet_forward(sd: SD, cfg: UNetConfig, x: Tensor, timesteps: Tensor, context: Tensor,
                  use_layerwise_context: bool = True, prefix: str = UNET_PREFIX,
-                 taps: Optional[dict] = None) -> Tensor:
+                 taps: Optional[dict] = None, placeholder_indices=None, conv_attn_kernel_size: int = -1) -> Tensor:
     """UNetModel.forward (openaimodel.py:827-1052) for the inference configuration:
     layerwise context [B*16, T, D] -> reshape(B,16,T,D).permute(1,0,2,3) (:863-866); the k-th
     cross-attention layer in forward order reads slice k (:876-883); U-Net skip stack (:982,1018-1019)."""
@@ -417,8 +457,13 @@ def unet_forward(sd: SD, cfg: UNetConfig, x: Tensor, timesteps: Tensor, context:
                 h = resblock(sd, p, h, emb)
             elif d[0] == "xfmr":
                 ctx = ctx_layers[ca_idx] if use_layerwise_context else context
+                # conv attention on every conditioned layer except CA layers 6-10 (kernel size forced to 1 there:
+                # openaimodel.py:922-932); placeholder_indices = (indices_B, indices_N) of one subject string
+                ca = None
+                if placeholder_indices is not None and conv_attn_kernel_size > 0:
+                    ca = (placeholder_indices, 1 if 6 <= ca_idx <= 10 else conv_attn_kernel_size)
                 ca_idx += 1
-                h = spatial_transformer(sd, p, h, ctx, cfg.num_heads, cfg.transformer_depth)
+                h = spatial_transformer(sd, p, h, ctx, cfg.num_heads, cfg.transformer_depth, conv_attn=ca)
             elif d[0] == "down":
                 h = _conv(sd, p + ".op", h, stride=2)                       # openaimodel.py:153-157
             elif d[0] == "up":

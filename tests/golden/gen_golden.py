@@ -134,6 +134,15 @@ def main():
         golden[f"tiny_tap_{k}_stats"] = np.array([flat.mean().item(), flat.std().item()], dtype=np.float64)
         golden[f"tiny_tap_{k}_sample"] = flat[:: max(1, flat.numel() // 64)][:64].numpy()
 
+    # ---- tiny UNet with the subject-token conv attention (use_conv_attn_kernel_size = 3; attention.py:208-216,
+    # util.py:701-879): sample 0 carries a 9-token subject at text positions 5..13, sample 1 does not ----
+    ph = {"z": (torch.zeros(9, dtype=torch.long), torch.arange(5, 14))}
+    info_ca = dict(extra_info(), use_conv_attn_kernel_size=3, placeholder2indices=ph)
+    eps_ca = net(x, tt, context=ctx, extra_info=info_ca)
+    golden["tiny_convattn_idx_b"], golden["tiny_convattn_idx_n"] = ph["z"][0].numpy(), ph["z"][1].numpy()
+    golden["tiny_convattn_eps"] = eps_ca.numpy()
+    assert (eps_ca[0] - eps[0]).abs().max() > 1e-4 and torch.equal(eps_ca[1], eps[1])
+
     # ---- tiny UNet driven by the reference DDIMSampler (S=5, annealed guidance [10,4]) ----
     class FakeLDM:
         """Minimal stand-in for LatentDiffusion: the attributes DDIMSampler reads (ddim.py:19,40-46)."""

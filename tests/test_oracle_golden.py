@@ -147,3 +147,16 @@ def test_tiny_vae_encoder_matches_reference(tiny):
     assert np.abs(mom.numpy() - ref).max() < 2e-5 * np.abs(ref).max()
     z = O.posterior_sample(torch.tensor(ref), torch.tensor(tiny["vae_enc_noise"]), cfg.scale_factor)
     assert np.abs(z.numpy() - tiny["vae_enc_z"]).max() < 1e-6 * np.abs(tiny["vae_enc_z"]).max()
+
+
+def test_tiny_unet_conv_attention_matches_reference(tiny):
+    """Subject-token conv attention (replace_rows_by_conv_attn, 3x3) inside the reference UNet vs the oracle."""
+    cfg = O.TINY_UNET
+    sd = O.synth_state_dict(O.unet_param_shapes(cfg), seed=11)
+    ph = (torch.tensor(tiny["tiny_convattn_idx_b"]), torch.tensor(tiny["tiny_convattn_idx_n"]))
+    eps = O.unet_forward(sd, cfg, torch.tensor(tiny["tiny_x"]), torch.tensor(tiny["tiny_t"]), torch.tensor(tiny["tiny_ctx"]),
+                         placeholder_indices=ph, conv_attn_kernel_size=3)
+    ref = tiny["tiny_convattn_eps"]
+    assert np.abs(eps.numpy() - ref).max() < 2e-5 * np.abs(ref).max()
+    assert np.abs(ref[0] - tiny["tiny_eps"][0]).max() > 1e-4    # the replacement changes sample 0 ...
+    assert np.array_equal(ref[1], tiny["tiny_eps"][1])           # ... and leaves the subject-free sample alone
