@@ -65,6 +65,7 @@ _SIGS = [
     ("af_arena_bytes", C.c_int64, [_P]),
     ("af_prof_enable", C.c_int, [C.c_int]),
     ("af_prof_reset", C.c_int, []),
+    ("af_set_conv_attn", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("af_vae_encode", C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("af_posterior_sample", C.c_int, [_P, _P, C.c_float, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("af_prof_set_stride", C.c_int, [C.c_int]),

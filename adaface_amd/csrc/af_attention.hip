@@ -340,6 +340,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     l_tot = l_run + __shfl_xor(l_run, 32, 64);
   }
   const float inv = 1.0f / l_tot;
+  if (p.lse && q_ok && h == 0)
+    p.lse[((long)blockIdx.z * p.H + blockIdx.y) * p.Nq + q] = m_run + __builtin_amdgcn_logf(l_tot);
   if (q_ok) {
 #pragma unroll
     for (int d = 0; d < DB; ++d)

@@ -194,4 +194,5 @@ struct AttnParams {
   long bsq, bsk, bsv, bso;       // batch strides (elements)
   int Nq, Nk, H;
   float scale;
+  float* lse;   // optional [B][H][Nq]: log2-domain log-sum-exp of the scaled scores (m + log2 l); null = off
 };

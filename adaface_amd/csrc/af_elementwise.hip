@@ -45,6 +45,107 @@ __global__ void cast_f32_kernel(const float* __restrict__ x, T* __restrict__ y, 
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     y[i] = from_f32<T>(x[i]);
 }
+// fp32 -> T cast of [rows][D] with a per-row source map (set_context: subject tokens moved to the end of the key list)
+template <typename T>
+__global__ void gather_rows_cast_kernel(const float* __restrict__ x, const int* __restrict__ rowmap,
+                                        T* __restrict__ y, long rows, int D) {
+  const long n = rows * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D;
+    y[i] = from_f32<T>(x[(long)rowmap[r] * D + (i - r * D)]);
+  }
+}
+
+// ---- subject-token convolutional attention (ldm/util.py:701-879 replace_rows_by_conv_attn, 3x3) ----
+// Step 1: pointwise scores of the nine subject keys: s9[bb][h][p][t] = scale * q[b][p][h] . k[b][S-9+t][h]
+// (the subject tokens sit at the END of the cached key list: set_context permutes them there).
+template <typename T>
+__global__ __launch_bounds__(256) void subj_scores_kernel(const T* __restrict__ q, int ldq, long bsq,
+                                                          const T* __restrict__ kv, int ldk, long bsk, int S,
+                                                          float* __restrict__ s9, int N, int H, int dh, float scale) {
+  __shared__ float ks[9 * 160];
+  const int h = blockIdx.y, b = blockIdx.z;
+  for (int i = threadIdx.x; i < 9 * dh; i += 256)
+    ks[i] = to_f32<T>(kv[(long)b * bsk + (long)(S - 9 + i / dh) * ldk + h * dh + (i % dh)]);
+  __syncthreads();
+  const int pp = blockIdx.x * 256 + threadIdx.x;
+  if (pp >= N) return;
+  const T* qp = q + (long)b * bsq + (long)pp * ldq + h * dh;
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  for (int c = 0; c < dh; c += 4) {
+    Quad<T> qv;
+    qv.load(qp + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float f = to_f32<T>(qv.e[e]);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = fmaf(f, ks[t * dh + c + e], acc[t]);
+    }
+  }
+  float* o = s9 + (((long)b * H + h) * N + pp) * 9;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) o[t] = acc[t] * scale;
+}
+
+// Step 2: conv scores A(y,x) = ks^-1.5 * sum_t s9[(y+ty-1, x+tx-1)][t] (zero outside the map), column j of the subject
+// = A shifted by (dy,dx) = (j/3-1, j%3-1) with zero fill, then the exact softmax merge of the nine replaced keys with
+// the flash result over the other S-9 keys:  out = (w_U O_U + sum_j e_j v_j) / (w_U + sum_j e_j),
+// w_U = 2^(lse_U - M), e_j = 2^(r_j log2e - M).  o holds O_U on entry and the merged output on exit.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_attn_merge_kernel(const float* __restrict__ s9, const float* __restrict__ lse,
+                                                              const T* __restrict__ kv, int ldk, long bsk, int S,
+                                                              T* __restrict__ o, int ldo, long bso, int N, int H, int dh,
+                                                              int Hh, int Ww) {
+  __shared__ float vs[9 * 160];
+  const int h = blockIdx.y, b = blockIdx.z;
+  for (int i = threadIdx.x; i < 9 * dh; i += 256)
+    vs[i] = to_f32<T>(kv[(long)b * bsk + (long)(S - 9 + i / dh) * ldk + H * dh + h * dh + (i % dh)]);   // V half
+  __syncthreads();
+  const int pp = blockIdx.x * 256 + threadIdx.x;
+  if (pp >= N) return;
+  const int y = pp / Ww, x = pp - y * Ww;
+  const float* sb = s9 + ((long)b * H + h) * N * 9;
+  const float inv_norm = 0.19245008972987526f;   // 3^-1.5
+  float r[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int yy = y - (j / 3 - 1), xx = x - (j % 3 - 1);
+    float a = 0.f;
+    if ((unsigned)yy < (unsigned)Hh && (unsigned)xx < (unsigned)Ww) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
+        if ((unsigned)y2 < (unsigned)Hh && (unsigned)x2 < (unsigned)Ww) a += sb[(long)(y2 * Ww + x2) * 9 + t];
+      }
+    }
+    r[j] = a * inv_norm * 1.44269504088896340736f;   // to the log2 domain of the flash kernel
+  }
+  const float L = lse[((long)b * H + h) * N + pp];
+  float M = L;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) M = fmaxf(M, r[j]);
+  const float wU = exp2f(L - M);
+  float den = wU;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { r[j] = exp2f(r[j] - M); den += r[j]; }
+  const float inv = 1.0f / den;
+  T* op = o + (long)b * bso + (long)pp * ldo + h * dh;
+  for (int c = 0; c < dh; c += 4) {
+    Quad<T> ov;
+    ov.load(op + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = wU * to_f32<T>(ov.e[e]);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) v = fmaf(r[j], vs[j * dh + c + e], v);
+      ov.e[e] = from_f32<T>(v * inv);
+    }
+    ov.store(op + c);
+  }
+}
+
 template <typename T>
 __global__ void cast_to_f32_kernel(const T* __restrict__ x, float* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -252,6 +353,26 @@ template <typename T> int af_launch_cast_f32(const float* x, void* y, long n, hi
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+template <typename T>
+int af_launch_gather_rows_cast(const float* x, const int* rowmap, void* y, long rows, int D, hipStream_t s) {
+  hipLaunchKernelGGL((gather_rows_cast_kernel<T>), EW_GRID(rows * D), dim3(256), 0, s, x, rowmap, reinterpret_cast<T*>(y),
+                     rows, D);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <typename T>
+int af_launch_conv_attn(const void* q, int ldq, long bsq, const void* kv, int ldk, long bsk, int S, float* s9,
+                        const float* lse, void* o, int ldo, long bso, int B, int N, int H, int dh, int Hh, int Ww,
+                        float scale, hipStream_t s) {
+  if (dh > 160 || dh % 4 != 0 || Hh * Ww != N) return -1;
+  dim3 grid((N + 255) / 256, H, B);
+  hipLaunchKernelGGL((subj_scores_kernel<T>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(q), ldq, bsq,
+                     reinterpret_cast<const T*>(kv), ldk, bsk, S, s9, N, H, dh, scale);
+  hipLaunchKernelGGL((conv_attn_merge_kernel<T>), grid, dim3(256), 0, s, s9, lse, reinterpret_cast<const T*>(kv), ldk, bsk,
+                     S, reinterpret_cast<T*>(o), ldo, bso, N, H, dh, Hh, Ww);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
 template <typename T> int af_launch_cast_to_f32(const void* x, float* y, long n, hipStream_t s) {
   hipLaunchKernelGGL((cast_to_f32_kernel<T>), EW_GRID(n), dim3(256), 0, s, reinterpret_cast<const T*>(x), y, n);
   HIP_CHECK_RET(hipGetLastError());
@@ -333,6 +454,9 @@ int af_launch_nchw_to_uint8(const float* x, uint8_t* y, int B, int HW, hipStream
   template int af_launch_nchw_to_nhwc<T>(const float*, void*, int, int, int, int, float, hipStream_t);        \
   template int af_launch_nhwc_to_nchw<T>(const void*, float*, int, int, int, int, hipStream_t);               \
   template int af_launch_cast_f32<T>(const float*, void*, long, hipStream_t);                                 \
+  template int af_launch_gather_rows_cast<T>(const float*, const int*, void*, long, int, hipStream_t);         \
+  template int af_launch_conv_attn<T>(const void*, int, long, const void*, int, long, int, float*, const float*, \
+                                      void*, int, long, int, int, int, int, int, int, float, hipStream_t);    \
   template int af_launch_cast_to_f32<T>(const void*, float*, long, hipStream_t);                              \
   template int af_launch_timestep_embedding<T>(const long long*, void*, int, int, hipStream_t);               \
   template int af_launch_silu<T>(const void*, void*, long, hipStream_t);                                      \

@@ -22,6 +22,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <string>
@@ -212,6 +213,14 @@ struct af_handle {
   std::vector<Linear> edown;
   int emid1 = -1, emid2 = -1;
   std::vector<VLevel> elevels;
+
+  // subject-token conv attention (af_set_conv_attn): kernel size (3, or <= 0 = off), the samples that carry the
+  // subject and the text positions of its ks*ks tokens (tap order)
+  int conv_ks = 0;
+  std::vector<int> conv_batch;
+  std::vector<int> conv_tokens;   // [conv_batch.size()][9]
+  int* ctx_rowmap = nullptr;      // device row map used by set_context when conv attention is on
+  size_t ctx_rowmap_n = 0;
 
   // runtime state
   Arena arena;
@@ -696,17 +705,21 @@ struct Runner {
     return DISPATCH(dt, af_launch_layernorm<bf16>(x.p, x.ld, x.npix(), x.C, N.gamma, N.beta, N.eps, y.p, y.ld, s),
                     af_launch_layernorm<float>(x.p, x.ld, x.npix(), x.C, N.gamma, N.beta, N.eps, y.p, y.ld, s));
   }
+  // samples [b0, b0 + nb) of the batch (nb < 0: all of o.B); lse: optional [nb][heads][Nq] log-sum-exp output
   int attention(const void* q, int ldq, long bsq, const void* k, int ldk, long bsk, const void* v, int ldv, long bsv,
-                Act& o, int Nq, int Nk, int heads, int dh) {
+                Act& o, int Nq, int Nk, int heads, int dh, int b0 = 0, int nb = -1, float* lse = nullptr) {
     AF_TRY(check(o));
     if (dry) return 0;
+    if (nb < 0) nb = o.B;
     AttnParams p;
-    p.q = q; p.k = k; p.v = v; p.o = o.p;
-    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = o.ld;
     p.bsq = bsq; p.bsk = bsk; p.bsv = bsv; p.bso = (long)Nq * o.ld;
+    p.q = elem_ptr(const_cast<void*>(q), b0 * p.bsq); p.k = elem_ptr(const_cast<void*>(k), b0 * p.bsk);
+    p.v = elem_ptr(const_cast<void*>(v), b0 * p.bsv); p.o = elem_ptr(o.p, b0 * p.bso);
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = o.ld;
     p.Nq = Nq; p.Nk = Nk; p.H = heads;
     p.scale = 1.0f / sqrtf((float)dh);
-    return DISPATCH(dt, af_launch_attention<bf16>(p, o.B, dh, s), af_launch_attention<float>(p, o.B, dh, s));
+    p.lse = lse;
+    return DISPATCH(dt, af_launch_attention<bf16>(p, nb, dh, s), af_launch_attention<float>(p, nb, dh, s));
   }
   int copy_channels(const Act& src, Act& dst, int off) {
     if (dry) return 0;
@@ -768,8 +781,46 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out) {
       af_set_error_msg("context not set for batch %d (af_set_context)", B);
       return AF_ERR_STATE;
     }
-    AF_TRY(R.attention(q.p, C, (long)N * C, kv.kv, 2 * C, (long)S * 2 * C, R.dry ? nullptr : R.elem_ptr(kv.kv, C),
-                       2 * C, (long)S * 2 * C, a, N, S, w.heads, w.dh));
+    const int ca_layer = (w.ca_slot + (int)d) / (int)w.blocks.size();
+    // subject-token conv attention: every conditioned layer except CA layers 6-10 (openaimodel.py:922-932)
+    const bool conv_attn = h->conv_ks == 3 && !h->conv_batch.empty() && !(ca_layer >= 6 && ca_layer <= 10);
+    if (!conv_attn) {
+      AF_TRY(R.attention(q.p, C, (long)N * C, kv.kv, 2 * C, (long)S * 2 * C, R.dry ? nullptr : R.elem_ptr(kv.kv, C),
+                         2 * C, (long)S * 2 * C, a, N, S, w.heads, w.dh));
+    } else {
+      // runs of consecutive samples with / without the subject: flash attention over all S keys, or over the first
+      // S-9 (the subject's keys were moved to the end by af_set_context) followed by the exact softmax merge with
+      // the nine convolutional score columns (af_launch_conv_attn)
+      const size_t mk3 = R.A.mark();
+      float* lse = reinterpret_cast<float*>(R.A.alloc((size_t)B * w.heads * N * sizeof(float)));
+      float* s9 = reinterpret_cast<float*>(R.A.alloc((size_t)B * w.heads * N * 9 * sizeof(float)));
+      if (!lse || !s9) { af_set_error_msg("arena exhausted (conv attention scratch)"); return AF_ERR_STATE; }
+      void* vptr = R.dry ? nullptr : R.elem_ptr(kv.kv, C);
+      int b0 = 0;
+      while (b0 < B) {
+        auto has = [&](int b) { return std::find(h->conv_batch.begin(), h->conv_batch.end(), b) != h->conv_batch.end(); };
+        const bool subj = has(b0);
+        int b1 = b0 + 1;
+        while (b1 < B && has(b1) == subj) ++b1;
+        const int nb = b1 - b0;
+        AF_TRY(R.attention(q.p, C, (long)N * C, kv.kv, 2 * C, (long)S * 2 * C, vptr, 2 * C, (long)S * 2 * C, a, N,
+                           subj ? S - 9 : S, w.heads, w.dh, b0, nb, subj ? lse : nullptr));
+        if (subj && !R.dry) {
+          const float scale = 1.0f / sqrtf((float)w.dh);
+          AF_TRY(DISPATCH(R.dt,
+                          af_launch_conv_attn<bf16>(R.elem_ptr(q.p, (long)b0 * N * C), C, (long)N * C,
+                                                    R.elem_ptr(kv.kv, (long)b0 * S * 2 * C), 2 * C, (long)S * 2 * C, S, s9, lse,
+                                                    R.elem_ptr(a.p, (long)b0 * N * a.ld), a.ld, (long)N * a.ld, nb, N, w.heads,
+                                                    w.dh, H, W, scale, R.s),
+                          af_launch_conv_attn<float>(R.elem_ptr(q.p, (long)b0 * N * C), C, (long)N * C,
+                                                     R.elem_ptr(kv.kv, (long)b0 * S * 2 * C), 2 * C, (long)S * 2 * C, S, s9, lse,
+                                                     R.elem_ptr(a.p, (long)b0 * N * a.ld), a.ld, (long)N * a.ld, nb, N, w.heads,
+                                                     w.dh, H, W, scale, R.s)));
+        }
+        b0 = b1;
+      }
+      R.A.release(mk3);
+    }
     Act t2 = R.alloc_act(B, H, W, C);
     AF_TRY(R.conv(blk.out2, a, t2, 1, 0, &t1, nullptr, 0));
     // --- x = ff(norm3(x)) + x ---
@@ -1159,6 +1210,7 @@ void af_destroy(af_handle* h) {
   hipDeviceSynchronize();
   for (void* p : h->owned) hipFree(p);
   for (auto& kv : h->ctx_kv) if (kv.kv) hipFree(kv.kv);
+  if (h->ctx_rowmap) hipFree(h->ctx_rowmap);
   if (h->ctx_cast) hipFree(h->ctx_cast);
   if (h->arena.base) hipFree(h->arena.base);
   if (h->stage) hipFree(h->stage);
@@ -1245,6 +1297,22 @@ static int check_loaded(af_handle* h, const char* prefix) {
   return 0;
 }
 
+int af_set_conv_attn(af_handle* h, int ks, int n_subj, const int* batch_idx, const int* token_idx) {
+  if (!h) { af_set_error_msg("af_set_conv_attn: null handle"); return AF_ERR_INVALID; }
+  if (ks <= 1 || n_subj <= 0) {   // off (kernel size 1 is the identity: util.py:705-706)
+    h->conv_ks = 0; h->conv_batch.clear(); h->conv_tokens.clear();
+    h->ctx_set = false;
+    return AF_OK;
+  }
+  if (ks != 3) { af_set_error_msg("af_set_conv_attn: kernel size %d (only 3x3 is built)", ks); return AF_ERR_INVALID; }
+  if (!batch_idx || !token_idx) { af_set_error_msg("af_set_conv_attn: null index arrays"); return AF_ERR_INVALID; }
+  h->conv_ks = ks;
+  h->conv_batch.assign(batch_idx, batch_idx + n_subj);
+  h->conv_tokens.assign(token_idx, token_idx + (size_t)n_subj * 9);
+  h->ctx_set = false;   // the cached K/V depend on the token order: af_set_context must follow
+  return AF_OK;
+}
+
 int af_set_context(af_handle* h, const float* ctx_dev, int Bf, int n_tokens, int layerwise, void* stream) {
   if (!h || !ctx_dev || Bf <= 0 || n_tokens <= 0) { af_set_error_msg("af_set_context: bad argument"); return AF_ERR_INVALID; }
   if (!h->cfg.build_unet) { af_set_error_msg("af_set_context: handle has no UNet"); return AF_ERR_STATE; }
@@ -1273,7 +1341,46 @@ int af_set_context(af_handle* h, const float* ctx_dev, int Bf, int n_tokens, int
       HIP_CHECK_RET(hipMalloc(&h->ctx_kv[i].kv, (size_t)Bf * n_tokens * 2 * C * esize(dt)));
     }
   }
-  AF_TRY(DISPATCH(dt, af_launch_cast_f32<bf16>(ctx_dev, h->ctx_cast, (long)n, s), af_launch_cast_f32<float>(ctx_dev, h->ctx_cast, (long)n, s)));
+  if (h->conv_ks == 3 && !h->conv_batch.empty()) {
+    // conv attention: in the samples that carry the subject, move its nine tokens (tap order) to the END of the token
+    // list of every context layer -- softmax is invariant to the key order, and the flash kernel can then leave them
+    // out by key count.  Row r of the cast context = (sample b, layer l, token i).
+    if (n_tokens <= 9) { af_set_error_msg("af_set_context: conv attention needs more than 9 tokens"); return AF_ERR_INVALID; }
+    const size_t rows = (size_t)Bf * L * n_tokens;
+    std::vector<int> map(rows);
+    for (int b = 0; b < Bf; ++b) {
+      std::vector<int> order(n_tokens);
+      for (int i = 0; i < n_tokens; ++i) order[i] = i;
+      auto it = std::find(h->conv_batch.begin(), h->conv_batch.end(), b);
+      if (it != h->conv_batch.end()) {
+        const int* tk = &h->conv_tokens[(size_t)(it - h->conv_batch.begin()) * 9];
+        std::vector<char> is_subj(n_tokens, 0);
+        for (int j = 0; j < 9; ++j) {
+          if (tk[j] < 0 || tk[j] >= n_tokens || is_subj[tk[j]]) { af_set_error_msg("af_set_context: bad subject token index %d", tk[j]); return AF_ERR_INVALID; }
+          is_subj[tk[j]] = 1;
+        }
+        int o = 0;
+        for (int i = 0; i < n_tokens; ++i) if (!is_subj[i]) order[o++] = i;
+        for (int j = 0; j < 9; ++j) order[o++] = tk[j];
+      }
+      for (int l = 0; l < L; ++l)
+        for (int i = 0; i < n_tokens; ++i)
+          map[((size_t)b * L + l) * n_tokens + i] = (int)(((size_t)b * L + l) * n_tokens + order[i]);
+    }
+    if (rows > h->ctx_rowmap_n) {
+      HIP_CHECK_RET(hipStreamSynchronize(s));
+      if (h->ctx_rowmap) hipFree(h->ctx_rowmap);
+      h->ctx_rowmap = nullptr;
+      HIP_CHECK_RET(hipMalloc(&h->ctx_rowmap, rows * sizeof(int)));
+      h->ctx_rowmap_n = rows;
+    }
+    HIP_CHECK_RET(hipMemcpyAsync(h->ctx_rowmap, map.data(), rows * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipStreamSynchronize(s));   // `map` is a pageable host temporary
+    AF_TRY(DISPATCH(dt, af_launch_gather_rows_cast<bf16>(ctx_dev, h->ctx_rowmap, h->ctx_cast, (long)rows, D, s),
+                    af_launch_gather_rows_cast<float>(ctx_dev, h->ctx_rowmap, h->ctx_cast, (long)rows, D, s)));
+  } else {
+    AF_TRY(DISPATCH(dt, af_launch_cast_f32<bf16>(ctx_dev, h->ctx_cast, (long)n, s), af_launch_cast_f32<float>(ctx_dev, h->ctx_cast, (long)n, s)));
+  }
   for (size_t i = 0; i < h->ca_list.size(); ++i) {
     const XfmrW& x = h->xf[h->ca_list[i].first];
     const XfmrBlockW& blk = x.blocks[h->ca_list[i].second];

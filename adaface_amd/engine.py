@@ -132,6 +132,18 @@ class Engine:
         check(self._lib.af_set_context(self._h, ptr(ctx), Bf, n_tokens, 1 if layerwise else 0, stream_ptr()),
               "af_set_context")
 
+    def set_conv_attn(self, ks: int, batch_idx=(), token_idx=()):
+        """Subject-token conv attention (attention.py:208-216): `batch_idx` samples carry the subject whose first nine
+        token positions are `token_idx[i]`.  ks <= 1 or no samples switches it off.  Invalidates the cached context."""
+        n = len(batch_idx)
+        bi = (C.c_int * max(n, 1))(*[int(b) for b in batch_idx])
+        flat = [int(t) for row in token_idx for t in row]
+        ti = (C.c_int * max(len(flat), 1))(*flat)
+        if n and len(flat) != 9 * n:
+            raise ValueError("set_conv_attn: nine token positions per subject sample")
+        check(self._lib.af_set_conv_attn(self._h, int(ks), n, bi, ti), "af_set_conv_attn")
+        self._ctx_key = None
+
     def unet_forward(self, x: torch.Tensor, t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = x.contiguous().float()
         t = t.contiguous().long()

@@ -74,6 +74,26 @@ class UNetModel(HipModule):
         super()._mark_dirty()
         object.__setattr__(self, "_ctx_key", None)  # cached K/V depend on the weights
 
+    @staticmethod
+    def _conv_attn_spec(ks, placeholder2indices):
+        """(ks, batch indices, token positions) for Engine.set_conv_attn from the reference's
+        extra_info['placeholder2indices'] = {subject string: (indices_B, indices_N)} (util.py:711-727): the M >= ks*ks
+        positions of each subject sample are consecutive in indices_N; the first ks*ks are used."""
+        if ks is None or ks <= 1 or not placeholder2indices:
+            return (0, (), ())
+        if ks != 3:
+            raise NotImplementedError(f"conv attention kernel size {ks}: only 3x3 (the inference setting) is built")
+        if len(placeholder2indices) != 1:
+            raise NotImplementedError("conv attention with several subject strings in one batch")
+        idx_b, idx_n = next(iter(placeholder2indices.values()))
+        idx_b = [int(v) for v in torch.as_tensor(idx_b).tolist()]
+        idx_n = [int(v) for v in torch.as_tensor(idx_n).tolist()]
+        uniq = sorted(set(idx_b))
+        M = len(idx_n) // len(uniq)
+        if M < ks * ks:
+            raise ValueError(f"{M} embeddings are not enough to cover a {ks}x{ks} kernel")
+        return (ks, tuple(uniq), tuple(tuple(idx_n[i * M: i * M + ks * ks]) for i in range(len(uniq))))
+
     @torch.no_grad()
     def forward(self, x, timesteps=None, context=None, y=None, context_in=None, extra_info=None, **kwargs):
         """x [B,C,H,W], timesteps [B], context [B*16,T,D] (layerwise) or [B,T,D]; returns eps [B,C,H,W] fp32.
@@ -85,9 +105,7 @@ class UNetModel(HipModule):
         info = extra_info if extra_info is not None else {}
         layerwise = bool(info.get("use_layerwise_context", False))
         ks = info.get("use_conv_attn_kernel_size", None)
-        if ks is not None and ks > 0 and info.get("placeholder2indices", None) is not None:
-            raise NotImplementedError("conv-attention row replacement (attention.py:208-216) is a 'next' row "
-                                      "(SURVEY.md §8f-1), not yet built")
+        conv = self._conv_attn_spec(ks, info.get("placeholder2indices", None))
         if info.get("apply_compel_cfg_prob", 0) > 0:
             raise NotImplementedError("compel-cfg context re-weighting (openaimodel.py:898-916) is a 'next' row")
         if info.get("img_mask", None) is not None or info.get("capture_distill_attn", False):
@@ -98,8 +116,9 @@ class UNetModel(HipModule):
         B = x.shape[0]
         # Hoisted cross-attention K/V are cached per context TENSOR OBJECT: a reference to it is kept so that its
         # id / storage cannot be recycled for another prompt while the cache is live (data_ptr alone is unsafe).
-        key = (id(context), getattr(context, "_version", 0), tuple(context.shape), layerwise, B)
+        key = (id(context), getattr(context, "_version", 0), tuple(context.shape), layerwise, B, conv)
         if key != self._ctx_key:
+            eng.set_conv_attn(*conv)
             eng.set_context(context.to(x.device), B, layerwise)
             object.__setattr__(self, "_ctx_key", key)
             object.__setattr__(self, "_ctx_ref", context)

@@ -71,6 +71,13 @@ const char* af_tensor_name(af_handle* h, int i);
 int af_tensor_loaded(af_handle* h, int i);
 int af_tensor_shape(af_handle* h, int i, int64_t* shape4 /* up to 4 dims, 0-terminated */);
 
+/* Subject-token convolutional attention inside the UNet's cross-attention layers
+ * (extra_info['use_conv_attn_kernel_size'] / ['placeholder2indices'], openaimodel.py:852-853,922-945;
+ * CrossAttention.forward attention.py:208-216; replace_rows_by_conv_attn ldm/util.py:701-879).
+ * ks = 3 (<= 1 or n_subj = 0 switches it off); batch_idx[n_subj] = samples of the CFG batch that carry the subject,
+ * token_idx[n_subj][9] = text positions of its first nine embeddings in tap order (host arrays).  Applies to every
+ * conditioned layer except CA layers 6-10, as the reference.  Must be followed by af_set_context. */
+int af_set_conv_attn(af_handle* h, int ks, int n_subj, const int* batch_idx, const int* token_idx);
 /* get_layer_context + to_k/to_v of all cross-attention layers, hoisted out of the
  * step loop (openaimodel.py:863-920, attention.py:195-196).  ctx_dev: fp32
  * [Bf*n_layers, n_tokens, context_dim] laid out as the reference does

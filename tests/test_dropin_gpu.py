@@ -42,6 +42,33 @@ def test_apply_model_matches_reference_golden(gpu, report, tiny_model):
     assert "ca_layers_activations" in cond[2]
 
 
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-4), ("bf16", 6e-2)])
+def test_apply_model_conv_attention_matches_reference(gpu, report, tiny_model, mode, tol):
+    """Subject-token 3x3 conv attention (extra_info use_conv_attn_kernel_size / placeholder2indices; attention.py:208-216,
+    util.py:701-879) through the drop-in UNet vs the reference UNet's output with the same extra_info."""
+    g = dict(np.load(GOLD / "golden_tiny.npz"))
+    x = torch.tensor(g["tiny_x"], device=gpu)
+    t = torch.tensor(g["tiny_t"], device=gpu)
+    emb, prompts, info = tiny_model.get_learned_conditioning(torch.tensor(g["tiny_ctx"], device=gpu))
+    info = dict(info, use_conv_attn_kernel_size=3,
+                placeholder2indices={"z": (torch.tensor(g["tiny_convattn_idx_b"]), torch.tensor(g["tiny_convattn_idx_n"]))})
+    tiny_model.set_compute_dtype(mode)
+    try:
+        eps = tiny_model.apply_model(x, t, (emb, prompts, info))
+        plain = tiny_model.apply_model(x, t, (emb, prompts, dict(info, placeholder2indices=None)))
+    finally:
+        tiny_model.set_compute_dtype("f32")
+    ref = g["tiny_convattn_eps"]
+    err = np.abs(eps.cpu().numpy() - ref).max() / np.abs(ref).max()
+    report(f"dropin apply_model + conv attention vs reference golden [{mode}]", err, float(np.abs(ref).max()), tol)
+    assert err < tol
+    # switching it off again restores the plain path (and its cached K/V order)
+    errp = np.abs(plain.cpu().numpy() - g["tiny_eps"]).max() / np.abs(g["tiny_eps"]).max()
+    assert errp < tol
+    if mode == "f32":
+        assert np.abs(eps.cpu().numpy()[0] - g["tiny_eps"][0]).max() > 1e-4    # the replacement does something
+
+
 def test_ddim_sampler_matches_reference_sampler(gpu, report, tiny_model):
     """DDIMSampler.sample with list guidance [10, 4] (annealing), CFG, eta 0, given x_T: final latent vs the latent
     the REFERENCE DDIMSampler produced driving the REFERENCE UNet (golden)."""
@@ -129,9 +156,12 @@ def test_out_of_scope_branches_raise(gpu, tiny_model):
     x = torch.tensor(g["tiny_x"], device=gpu)
     t = torch.tensor(g["tiny_t"], device=gpu)
     emb, prompts, info = tiny_model.get_learned_conditioning(torch.tensor(g["tiny_ctx"], device=gpu))
-    bad = dict(info, use_conv_attn_kernel_size=3, placeholder2indices={"z": (torch.tensor([0]), torch.tensor([1]))})
+    bad = dict(info, apply_compel_cfg_prob=0.5)
     with pytest.raises(NotImplementedError):
         tiny_model.apply_model(x, t, (emb, prompts, bad))
+    short = dict(info, use_conv_attn_kernel_size=3, placeholder2indices={"z": (torch.tensor([0]), torch.tensor([1]))})
+    with pytest.raises(ValueError):   # one embedding cannot cover a 3x3 kernel (util.py:732)
+        tiny_model.apply_model(x, t, (emb, prompts, short))
     with pytest.raises(NotImplementedError):
         tiny_model.get_learned_conditioning(["a photo of a z"])
 
