@@ -74,6 +74,42 @@ class UNetModel(HipModule):
         super()._mark_dirty()
         object.__setattr__(self, "_ctx_key", None)  # cached K/V depend on the weights
 
+    def _compel_cfg(self, context, B, info):
+        """Inference-time compel cfg (openaimodel.py:898-916 + prob_apply_compel_cfg, util.py:2063-2094): per conditioned
+        layer, with probability apply_compel_cfg_prob, the context of the FIRST half of the batch becomes
+        (ctx - empty) * 1.1**level + empty.  The Python `random` draws are made in the reference's order (one per layer,
+        then the level and two inner draws when it applies), so a seeded run re-weights the same layers.  Returns the
+        re-weighted context and whether it may be cached (prob >= 1 and a degenerate level range: the reference
+        re-draws on every forward otherwise).  The arithmetic is af_lincomb: w*ctx + (1-w)*empty."""
+        import random
+        from adaface_amd import ops
+        empty, rng, prob = info.get("empty_context", None), info.get("compel_cfg_weight_level_range", None), info["apply_compel_cfg_prob"]
+        if empty is None or rng is None:
+            return context, True
+        is_range = isinstance(rng, (list, tuple))
+        deterministic = prob >= 1 and (not is_range or rng[0] == rng[1])
+        key = ("compel", id(context), getattr(context, "_version", 0), id(empty), prob, tuple(rng) if is_range else rng)
+        if deterministic and getattr(self, "_compel_key", None) == key:
+            return self._compel_ctx, True
+        L = 16
+        ctx = context.reshape(B, L, -1, context.shape[-1]).clone()
+        half = B // 2
+        e = empty.to(ctx.device, torch.float32).expand(half, *ctx.shape[2:]).contiguous()
+        for l in range(L):
+            if random.random() > prob:
+                continue
+            level = random.uniform(*rng) if is_range else rng
+            random.random(); random.random()          # the recursive calls on (v, k) draw once each (util.py:2077)
+            w = 1.1 ** level
+            if half > 0:
+                ctx[:half, l] = ops.lincomb([(ctx[:half, l].contiguous(), w), (e, 1.0 - w)])
+        ctx = ctx.reshape(context.shape)
+        if deterministic:
+            object.__setattr__(self, "_compel_key", key)
+            object.__setattr__(self, "_compel_ctx", ctx)
+            object.__setattr__(self, "_compel_refs", (context, empty))
+        return ctx, deterministic
+
     @staticmethod
     def _conv_attn_spec(ks, placeholder2indices):
         """(ks, batch indices, token positions) for Engine.set_conv_attn from the reference's
@@ -106,21 +142,22 @@ class UNetModel(HipModule):
         layerwise = bool(info.get("use_layerwise_context", False))
         ks = info.get("use_conv_attn_kernel_size", None)
         conv = self._conv_attn_spec(ks, info.get("placeholder2indices", None))
-        if info.get("apply_compel_cfg_prob", 0) > 0:
-            raise NotImplementedError("compel-cfg context re-weighting (openaimodel.py:898-916) is a 'next' row")
         if info.get("img_mask", None) is not None or info.get("capture_distill_attn", False):
             raise NotImplementedError("img_mask / capture_distill_attn are training-time options")
         if info.get("iter_type", "normal_recon") == "mix_hijk":
             raise NotImplementedError("iter_type 'mix_hijk' (separate k/v contexts) is a training-time option")
         eng = self.engine(x.device)
         B = x.shape[0]
+        cache_ok = True
+        if layerwise and info.get("apply_compel_cfg_prob", 0) > 0:
+            context, cache_ok = self._compel_cfg(context.to(x.device), B, info)
         # Hoisted cross-attention K/V are cached per context TENSOR OBJECT: a reference to it is kept so that its
         # id / storage cannot be recycled for another prompt while the cache is live (data_ptr alone is unsafe).
         key = (id(context), getattr(context, "_version", 0), tuple(context.shape), layerwise, B, conv)
-        if key != self._ctx_key:
+        if key != self._ctx_key or not cache_ok:
             eng.set_conv_attn(*conv)
             eng.set_context(context.to(x.device), B, layerwise)
-            object.__setattr__(self, "_ctx_key", key)
+            object.__setattr__(self, "_ctx_key", key if cache_ok else None)
             object.__setattr__(self, "_ctx_ref", context)
         out = eng.unet_forward(x, timesteps.to(x.device))
         if extra_info is not None:

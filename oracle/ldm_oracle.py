@@ -436,7 +436,8 @@ def spatial_transformer(sd: SD, p: str, x: Tensor, ctx: Optional[Tensor], heads:
 
 def unet_forward(sd: SD, cfg: UNetConfig, x: Tensor, timesteps: Tensor, context: Tensor,
                  use_layerwise_context: bool = True, prefix: str = UNET_PREFIX,
-                 taps: Optional[dict] = None, placeholder_indices=None, conv_attn_kernel_size: int = -1) -> Tensor:
+                 taps: Optional[dict] = None, placeholder_indices=None, conv_attn_kernel_size: int = -1,
+                 compel_cfg=None) -> Tensor:
     """UNetModel.forward (openaimodel.py:827-1052) for the inference configuration:
     layerwise context [B*16, T, D] -> reshape(B,16,T,D).permute(1,0,2,3) (:863-866); the k-th
     cross-attention layer in forward order reads slice k (:876-883); U-Net skip stack (:982,1018-1019)."""
@@ -445,6 +446,14 @@ def unet_forward(sd: SD, cfg: UNetConfig, x: Tensor, timesteps: Tensor, context:
                F.silu(_lin(sd, prefix + "time_embed.0", timestep_embedding(timesteps, cfg.model_channels))))
     if use_layerwise_context:
         ctx_layers = context.reshape(B, cfg.n_context_layers, -1, context.shape[-1]).permute(1, 0, 2, 3)
+        if compel_cfg is not None:
+            # inference-time compel cfg with apply_compel_cfg_prob = 1 and a degenerate level range (the setting of
+            # stable_txt2img.py:680-682): every conditioned layer's context of the FIRST half of the batch becomes
+            # (ctx - empty) * 1.1**level + empty (openaimodel.py:898-916, util.py:2063-2094)
+            empty, level = compel_cfg
+            w = 1.1 ** level
+            ctx_layers = ctx_layers.clone()
+            ctx_layers[:, : B // 2] = (ctx_layers[:, : B // 2] - empty) * w + empty
     ca_idx = 0
 
     def run(block_prefix: str, descs, h: Tensor) -> Tensor:

@@ -143,6 +143,16 @@ def main():
     golden["tiny_convattn_eps"] = eps_ca.numpy()
     assert (eps_ca[0] - eps[0]).abs().max() > 1e-4 and torch.equal(eps_ca[1], eps[1])
 
+    # ---- tiny UNet with inference-time compel cfg (apply_compel_cfg_prob = 1, level range (2, 2), as
+    # stable_txt2img.py:680-682 sets it; openaimodel.py:898-916, util.py:2063-2094) ----
+    g3 = torch.Generator().manual_seed(777)
+    empty = torch.randn(1, 77, cfg.context_dim, generator=g3)
+    info_cc = dict(extra_info(), apply_compel_cfg_prob=1.0, compel_cfg_weight_level_range=(2.0, 2.0), empty_context=empty)
+    eps_cc = net(x, tt, context=ctx, extra_info=info_cc)
+    golden["tiny_compel_empty"] = empty.numpy()
+    golden["tiny_compel_eps"] = eps_cc.numpy()
+    assert (eps_cc[0] - eps[0]).abs().max() > 1e-4 and torch.equal(eps_cc[1], eps[1])
+
     # ---- tiny UNet driven by the reference DDIMSampler (S=5, annealed guidance [10,4]) ----
     class FakeLDM:
         """Minimal stand-in for LatentDiffusion: the attributes DDIMSampler reads (ddim.py:19,40-46)."""

@@ -69,6 +69,30 @@ def test_apply_model_conv_attention_matches_reference(gpu, report, tiny_model, m
         assert np.abs(eps.cpu().numpy()[0] - g["tiny_eps"][0]).max() > 1e-4    # the replacement does something
 
 
+def test_apply_model_compel_cfg_matches_reference(gpu, report, tiny_model):
+    """Inference-time compel cfg (stable_txt2img.py:680-682 -> openaimodel.py:898-916): context of the cond half
+    re-weighted against the empty prompt's, every layer (prob 1, level 2)."""
+    g = dict(np.load(GOLD / "golden_tiny.npz"))
+    x = torch.tensor(g["tiny_x"], device=gpu)
+    t = torch.tensor(g["tiny_t"], device=gpu)
+    emb, prompts, info = tiny_model.get_learned_conditioning(torch.tensor(g["tiny_ctx"], device=gpu))
+    info = dict(info, apply_compel_cfg_prob=1.0, compel_cfg_weight_level_range=(2.0, 2.0),
+                empty_context=torch.tensor(g["tiny_compel_empty"], device=gpu))
+    eps = tiny_model.apply_model(x, t, (emb, prompts, info))
+    eps2 = tiny_model.apply_model(x, t, (emb, prompts, info))      # cached re-weighted context
+    ref = g["tiny_compel_eps"]
+    err = np.abs(eps.cpu().numpy() - ref).max() / np.abs(ref).max()
+    report("dropin apply_model + compel cfg vs reference golden [f32]", err, float(np.abs(ref).max()), 2e-4)
+    assert err < 2e-4 and torch.equal(eps, eps2)
+    # probability 0.5: the layers are drawn with Python's `random` as the reference does -> reproducible under a seed
+    import random
+    info5 = dict(info, apply_compel_cfg_prob=0.5)
+    random.seed(11); a = tiny_model.apply_model(x, t, (emb, prompts, info5))
+    random.seed(11); b = tiny_model.apply_model(x, t, (emb, prompts, info5))
+    random.seed(12); c = tiny_model.apply_model(x, t, (emb, prompts, info5))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
 def test_ddim_sampler_matches_reference_sampler(gpu, report, tiny_model):
     """DDIMSampler.sample with list guidance [10, 4] (annealing), CFG, eta 0, given x_T: final latent vs the latent
     the REFERENCE DDIMSampler produced driving the REFERENCE UNet (golden)."""
@@ -156,7 +180,7 @@ def test_out_of_scope_branches_raise(gpu, tiny_model):
     x = torch.tensor(g["tiny_x"], device=gpu)
     t = torch.tensor(g["tiny_t"], device=gpu)
     emb, prompts, info = tiny_model.get_learned_conditioning(torch.tensor(g["tiny_ctx"], device=gpu))
-    bad = dict(info, apply_compel_cfg_prob=0.5)
+    bad = dict(info, iter_type="mix_hijk")
     with pytest.raises(NotImplementedError):
         tiny_model.apply_model(x, t, (emb, prompts, bad))
     short = dict(info, use_conv_attn_kernel_size=3, placeholder2indices={"z": (torch.tensor([0]), torch.tensor([1]))})

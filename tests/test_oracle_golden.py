@@ -160,3 +160,13 @@ def test_tiny_unet_conv_attention_matches_reference(tiny):
     assert np.abs(eps.numpy() - ref).max() < 2e-5 * np.abs(ref).max()
     assert np.abs(ref[0] - tiny["tiny_eps"][0]).max() > 1e-4    # the replacement changes sample 0 ...
     assert np.array_equal(ref[1], tiny["tiny_eps"][1])           # ... and leaves the subject-free sample alone
+
+
+def test_tiny_unet_compel_cfg_matches_reference(tiny):
+    cfg = O.TINY_UNET
+    sd = O.synth_state_dict(O.unet_param_shapes(cfg), seed=11)
+    eps = O.unet_forward(sd, cfg, torch.tensor(tiny["tiny_x"]), torch.tensor(tiny["tiny_t"]), torch.tensor(tiny["tiny_ctx"]),
+                         compel_cfg=(torch.tensor(tiny["tiny_compel_empty"]), 2.0))
+    ref = tiny["tiny_compel_eps"]
+    assert np.abs(eps.numpy() - ref).max() < 2e-5 * np.abs(ref).max()
+    assert np.array_equal(ref[1], tiny["tiny_eps"][1])   # only the first half of the batch is re-weighted
