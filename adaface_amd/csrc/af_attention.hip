@@ -53,10 +53,10 @@ template <typename T, int DH> struct AttnCfg {
   static constexpr bool ONES = BF && (DH % 32) != 0;
   // a free padding slot d = DH in the QK^T K-dimension (dh = 40: 80 -> 96 bytes) carries "1.0" on the K side and
   // "-m_ref" (the per-query running softmax reference, kept bf16-representable) on the Q side: the MFMA then returns
-  // s - m_ref directly and the 32 v_sub per tile disappear; m_ref moves only when a tile's maximum exceeds it.
-  // (measured on MI355X: the two code paths raise dh=40 from 152 to 190 VGPRs, 3 -> 2 waves per SIMD, and the kernel
-  //  gets 24 % slower, so the variant is compiled out; kept for the next round's register work)
-  static constexpr bool MREF = false && BF && ((DH * 2) % 32) != 0;
+  // s - m_ref directly and the 32 v_sub per tile disappear; m_ref moves only on the first tile or when a score rises
+  // 2^24 above it.  With ONE exp loop behind a rare "move the reference" fix-up the kernel needs 132 VGPRs (the first
+  // version with two unrolled loops needed 190 and lost); dh = 40 self-attention 612 -> 539 us, 515 us at 4 waves/SIMD.
+  static constexpr bool MREF = BF && ((DH * 2) % 32) != 0;
   static constexpr int MREF_STEP = (DH * 2) / 32, MREF_HALF = ((DH * 2) % 32) / 16, MREF_ELEM = (((DH * 2) % 32) % 16) / 2;
 };
 
@@ -81,8 +81,7 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
   return r;
 }
 
-template <typename T, int DH>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+template <typename T, int DH> __device__ __forceinline__ void attn_body(const AttnParams& p) {
   using C = AttnCfg<T, DH>;
   constexpr bool BF = C::BF;
   constexpr int EPC = C::EPC, FS = C::FS, KROW = C::KROW, DB = C::DB, CPR = C::CPR, NLD = C::NLD;
@@ -225,22 +224,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     float mx = max3f(mxa, mxb, mxc);
     mx = xhalf_max(fmaxf(mx, mxd));
     if constexpr (C::MREF) {
-      // s already holds score - m_ref.  The reference moves (rarely after the first tiles) when mx > 0.
-      const bool move = (t == 0) || mx > 0.f;
-      if (__builtin_amdgcn_ballot_w64(move) != 0) {
+      // s already holds score - m_ref (the MFMA added the Q-side "-m_ref" slot times the K-side 1.0), so the common path
+      // is exp2(s) with no per-element subtraction.  The reference only moves on the first tile or when a score gets
+      // more than 2^MREF_HEADROOM above it (fp32 / bf16 exponents have room; the final O / l ratio is scale free).
+      constexpr float MREF_HEADROOM = 24.0f;
+      const bool move = (t == 0) || mx > MREF_HEADROOM;
+      if (__builtin_amdgcn_ballot_w64(move) != 0) {   // rare after the first tile
         const float m_new = move ? bf16_ceil(m_run + mx) : m_run;
         const float delta = m_new - m_run;  // exact: both are bf16 values
         const float alpha = __builtin_amdgcn_exp2f(-delta);
-        float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(s[kb][r] - delta);
-            s[kb][r] = pv;
-            if constexpr (!C::ONES) psum += pv;
-          }
-        if constexpr (!C::ONES) l_run = l_run * alpha + psum;
+          for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
+        if constexpr (!C::ONES) l_run *= alpha;
 #pragma unroll
         for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -252,18 +249,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
           v.e[C::MREF_ELEM] = from_f32<T>(-m_new);
           qf[C::MREF_STEP] = v.u;
         }
-      } else {
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(s[kb][r]);
-            s[kb][r] = pv;
-            if constexpr (!C::ONES) psum += pv;
-          }
-        if constexpr (!C::ONES) l_run += psum;
       }
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(s[kb][r]);
+          s[kb][r] = pv;
+          if constexpr (!C::ONES) psum += pv;
+        }
+      if constexpr (!C::ONES) l_run += psum;
     } else {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -358,16 +354,30 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   }
 }
 
+template <typename T, int DH> __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) { attn_body<T, DH>(p); }
+// dh = 40 (the 64x64 self-attention, 16 % of a denoising step): 132 VGPRs as written; capped at 128 the kernel runs
+// four waves per SIMD instead of three (LDS allows four workgroups per CU)
+template <typename T, int DH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_kernel_w4(const AttnParams p) {
+  attn_body<T, DH>(p);
+}
+
 template <typename T, int DH> static int launch_attn(const AttnParams& p, int B, hipStream_t stream) {
   using C = AttnCfg<T, DH>;
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<T, DH>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel_w4<T, DH>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_set = true;
   }
   dim3 grid((p.Nq + 127) / 128, p.H, B);
-  hipLaunchKernelGGL((attn_kernel<T, DH>), grid, dim3(256), C::LDS_BYTES, stream, p);
+  static const int w4 = getenv("AF_ATTN_W4") ? atoi(getenv("AF_ATTN_W4")) : 1;
+  if (C::BF && DH == 40 && w4)
+    hipLaunchKernelGGL((attn_kernel_w4<T, DH>), grid, dim3(256), C::LDS_BYTES, stream, p);
+  else
+    hipLaunchKernelGGL((attn_kernel<T, DH>), grid, dim3(256), C::LDS_BYTES, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
