@@ -1133,7 +1133,7 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
       }
       const long nbs = nb * s;
       const double fill = (double)nbs / (double)(((nbs + 255) / 256) * 256);
-      if (fill >= env_int("AF_GEMM_PP_MINFILL", 70) * 0.01 && p.M >= 512) {
+      if (fill >= env_int("AF_GEMM_PP_MINFILL", 50) * 0.01 && p.M >= 512) {
         pl.tile = cand;
         pl.splitk = s;
         pl.halo_tw = 0;
