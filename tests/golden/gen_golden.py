@@ -197,6 +197,18 @@ def main():
                            unconditional_conditioning=(uc, [""] * B, extra_info()), eta=0.0, x_T=x_T)
     golden["ddim_S6_samples"] = s6.numpy()
 
+    # ---- img2img tail on the tiny UNet: stochastic_encode at DDIM index 3 of 5, then DDIMSampler.decode with the
+    # annealed guidance 5 -> 2 (ddim.py:299-350) ----
+    g4 = torch.Generator().manual_seed(2024)
+    sampler.make_schedule(ddim_num_steps=5, ddim_eta=0.0, verbose=False)
+    z0 = torch.randn(B, 4, H, H, generator=g4)
+    enc_noise = torch.randn(B, 4, H, H, generator=g4)
+    z_enc = sampler.stochastic_encode(z0, torch.tensor([3] * B), noise=enc_noise)
+    z_dec = sampler.decode(z_enc, (c, ["p"] * B, extra_info()), 3, guidance_scale=5.0,
+                           unconditional_conditioning=(uc, [""] * B, extra_info()))
+    golden["i2i_z0"], golden["i2i_noise"] = z0.numpy(), enc_noise.numpy()
+    golden["i2i_z_enc"], golden["i2i_z_dec"] = z_enc.numpy(), z_dec.numpy()
+
     # ---- tiny VAE decoder ----
     vcfg = O.TINY_VAE
     vsd = O.synth_state_dict(O.vae_param_shapes(vcfg), seed=12)

@@ -125,6 +125,26 @@ def test_ddim_sampler_matches_reference_sampler(gpu, report, tiny_model):
     assert err < 1e-3
 
 
+def test_img2img_encode_decode_matches_reference_sampler(gpu, report, tiny_model):
+    """DDIMSampler.stochastic_encode + .decode (ddim.py:299-350: the img2img tail, guidance annealed 5 -> 2 over the
+    remaining steps) vs the reference sampler driving the reference UNet."""
+    from ldm.models.diffusion.ddim import DDIMSampler
+    g = dict(np.load(GOLD / "golden_tiny.npz"))
+    c = tiny_model.get_learned_conditioning(torch.tensor(g["ddim_c"], device=gpu))
+    uc = tiny_model.get_learned_conditioning(torch.tensor(g["ddim_uc"], device=gpu))
+    sampler = DDIMSampler(tiny_model)
+    sampler.make_schedule(ddim_num_steps=5, ddim_eta=0.0, verbose=False)
+    z_enc = sampler.stochastic_encode(torch.tensor(g["i2i_z0"], device=gpu), torch.tensor([3], device=gpu),
+                                      noise=torch.tensor(g["i2i_noise"], device=gpu))
+    e1 = np.abs(z_enc.cpu().numpy() - g["i2i_z_enc"]).max() / np.abs(g["i2i_z_enc"]).max()
+    z_dec = sampler.decode(z_enc, c, 3, guidance_scale=5.0, unconditional_conditioning=uc)
+    ref = g["i2i_z_dec"]
+    e2 = np.abs(z_dec.cpu().numpy() - ref).max() / np.abs(ref).max()
+    report("dropin stochastic_encode vs reference [f32]", e1, 1.0, 1e-5)
+    report("dropin DDIMSampler.decode (img2img, 3 of 5 steps) vs reference sampler [f32]", e2, float(np.abs(ref).max()), 1e-3)
+    assert e1 < 1e-5 and e2 < 1e-3
+
+
 def test_plms_sampler_matches_reference_sampler(gpu, report, tiny_model):
     """PLMSSampler (the reference's --plms path): uncond-first CFG batch, Adams-Bashforth multistep."""
     from ldm.models.diffusion.plms import PLMSSampler
