@@ -302,6 +302,19 @@ def main():
         full["sd15_vae_img_crop"] = img[:, :, 192:320, 192:320].numpy()
         full["sd15_vae_img_stats"] = np.array([img.mean().item(), img.std().item(), img.abs().max().item()])
         full["sd15_vae_img_sub8"] = img[:, :, ::8, ::8].numpy()
+        # full-size SD-1.5 VAE encoder + quant_conv (34.16 M parameters) on one 512x512 image
+        from ldm.modules.diffusionmodules.model import Encoder
+        g5 = torch.Generator().manual_seed(31337)
+        esd = O.synth_state_dict(O.vae_encoder_param_shapes(vcfg), seed=23)
+        enc = Encoder(ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], dropout=0.0,
+                      in_channels=3, resolution=256, z_channels=4, double_z=True).eval()
+        load(enc, esd, O.VAE_PREFIX + "encoder.")
+        qc = torch.nn.Conv2d(8, 8, 1)
+        qc.weight.data.copy_(esd[O.VAE_PREFIX + "quant_conv.weight"])
+        qc.bias.data.copy_(esd[O.VAE_PREFIX + "quant_conv.bias"])
+        ximg = torch.rand(1, 3, 512, 512, generator=g5) * 2.0 - 1.0
+        full["sd15_enc_x_seed"] = np.array([31337])     # the image is regenerated from the seed (3 MB otherwise)
+        full["sd15_enc_moments"] = qc(enc(ximg)).numpy()
         np.savez_compressed(OUT / "golden_sd15.npz", **full)
         print("wrote", OUT / "golden_sd15.npz")
 

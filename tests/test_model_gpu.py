@@ -200,3 +200,21 @@ def test_sd15_vae_golden(gpu, report, dtype):
     assert np.isfinite(img).all()
     assert err < TOL[dtype], err
     eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_sd15_vae_encoder_golden(gpu, report, dtype):
+    """Full-size VAE encoder (512x512 image -> posterior moments [1,8,64,64]) vs the reference Encoder + quant_conv."""
+    from adaface_amd.engine import Engine
+    g = dict(np.load(GOLD / "golden_sd15.npz"))
+    cfg = O.SD15_VAE
+    sd = O.synth_state_dict(O.vae_encoder_param_shapes(cfg), seed=23)
+    eng = Engine(dtype=dtype, vae=dict(_vae_kwargs(cfg), encoder=True, in_channels=3))
+    eng.load_state_dict(sd, strict=False)   # encoder side only
+    x = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(int(g["sd15_enc_x_seed"][0]))) * 2.0 - 1.0
+    mom = eng.vae_encode(x.to(gpu)).cpu().numpy()
+    ref = g["sd15_enc_moments"]
+    err = _rel(mom, ref)
+    report(f"sd15_vae encoder moments vs reference golden [{dtype}]", err, float(np.abs(ref).max()), TOL[dtype])
+    assert mom.shape == ref.shape and err < TOL[dtype], err
+    eng.close()

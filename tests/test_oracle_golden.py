@@ -170,3 +170,14 @@ def test_tiny_unet_compel_cfg_matches_reference(tiny):
     ref = tiny["tiny_compel_eps"]
     assert np.abs(eps.numpy() - ref).max() < 2e-5 * np.abs(ref).max()
     assert np.array_equal(ref[1], tiny["tiny_eps"][1])   # only the first half of the batch is re-weighted
+
+
+def test_sd15_vae_encoder_matches_reference():
+    g = np.load(GOLD / "golden_sd15.npz")
+    cfg = O.SD15_VAE
+    sd = O.synth_state_dict(O.vae_encoder_param_shapes(cfg), seed=23)
+    assert sum(int(np.prod(v.shape)) for v in sd.values()) == 34_163_592 + 72   # Encoder + quant_conv
+    x = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(int(g["sd15_enc_x_seed"][0]))) * 2.0 - 1.0
+    mom = O.vae_encode_moments(sd, cfg, x)
+    ref = g["sd15_enc_moments"]
+    assert np.abs(mom.numpy() - ref).max() < 5e-5 * np.abs(ref).max()
