@@ -2,7 +2,8 @@
 
 A functional fp32 restatement, in plain torch CPU ops, of what the reference computes on
 the path DDIMSampler.sample -> LatentDiffusion.apply_model -> UNetModel.forward and
-AutoencoderKL.decode.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+AutoencoderKL.decode, plus the "next" rows built so far: PLMSSampler, the subject-token conv
+attention and compel-cfg inside the UNet call, AutoencoderKL.encode and the posterior sample.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
 leg may import this module; the product (adaface_amd/) never does and has no CPU path.
 
 Pinning: the reference ships no tests or golden vectors for this path (SURVEY.md §4,
