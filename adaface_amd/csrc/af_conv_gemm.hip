@@ -709,6 +709,51 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
   const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
   const T* __restrict__ rowb = reinterpret_cast<const T*>(p.rowbias);
   float* slab = p.splitk > 1 ? reinterpret_cast<float*>(p.ws) + (long)zk * p.M * p.N : nullptr;
+  if (p.dbg_nobarrier == 2 || (p.dbg_nobarrier == 0 && (geglu || slab))) {
+    // Direct epilogue: every lane stores its 4 consecutive output channels of a pixel straight from the accumulator
+    // (8-byte stores, four lanes covering a 32-byte run of the row; fp32 split-K slabs: 16-byte stores).  No LDS pass,
+    // no workgroup barriers; the time-bias / residual quads of a row group are fetched before its first store.
+    // Measured against the two-pass LDS transposition below: GEGLU -4...-6 %, split-K slabs -2...-5 %, everything else
+    // within +-1 %, so it is the default for those two and AF_PP_DIRECT = 0 / 1 forces either.
+    const int nblk = geglu ? NI / 2 : NI;
+    const int cbase = ncol0 + g * HNo + cl;
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int m = m0 + wq * 64 + j * 16 + (lane & 15);
+      if (m >= p.M) continue;
+      if (slab) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          if (i < nblk) *reinterpret_cast<f32x4*>(slab + (long)m * p.N + cbase + i * 16) = acc[i][j];
+        continue;
+      }
+      Quad<T> rq[NI], bq[NI];
+      if (rowb) {
+        const T* rp = rowb + (long)(m / HoWo) * p.ldrb + cbase;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) if (i < nblk) bq[i].load(rp + i * 16);
+      }
+      if (res) {
+        const T* rp = res + (long)m * p.ldr + cbase;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) if (i < nblk) rq[i].load(rp + i * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if (i >= nblk) continue;
+        Quad<T> o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][j][e];
+          if (rowb) v += to_f32<T>(bq[i].e[e]);
+          if (res) v += to_f32<T>(rq[i].e[e]);
+          o.e[e] = from_f32<T>(v);
+        }
+        o.store(out + (long)m * p.ldo + cbase + i * 16);
+      }
+    }
+    return;
+  }
   constexpr int ITEMS = BN / 32;                    // 8-column vectors per thread and pass (GEGLU: half of them)
   const int nitems = geglu ? ITEMS / 2 : ITEMS;
 #pragma unroll 1
@@ -1253,6 +1298,10 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   g_af_last_plan = pl;
   p.group_m = pl.group_m > 0 ? pl.group_m : 1;
   p.dbg_nobarrier = env_int("AF_DEBUG_NOBARRIER", 0);  // timing diagnostic only: results are WRONG when set
+  if (pl.tile >= 4) {   // ping-pong kernel: the field selects the epilogue instead (0 = direct for GEGLU / split-K slabs, 1 = LDS, 2 = direct)
+    static const int pp_direct = env_int("AF_PP_DIRECT", -1);
+    p.dbg_nobarrier = pp_direct < 0 ? 0 : (pp_direct ? 2 : 1);
+  }
   AfProfScope prof(AF_K_CONV_GEMM, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K) * batch,
                    ((double)p.M * p.K / (p.ks * p.ks) + (double)p.N * p.K + (double)p.M * p.N) * batch * sizeof(T));
   int rc;
