@@ -293,3 +293,65 @@ def test_to_uint8(gpu):
     # identical arithmetic up to fp32 rounding of x*255: allow off-by-one on exact boundaries
     assert (abs(got.astype(int) - ref.astype(int)) <= 1).all()
     assert (got != ref).mean() < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Size-independent properties at the benchmark's full SD-1.5 shapes (Bf = 16), where a CPU reference of the whole
+# tensor would take minutes: linearity of the convolution, invariance of attention to the key order, invariance of
+# GroupNorm to an affine change of its input, bitwise run-to-run determinism.  bf16 kernels, fp32 comparisons.
+# ---------------------------------------------------------------------------------------------------------------
+def test_fullsize_conv_linearity_and_determinism(gpu, report):
+    """conv3x3 320->320 at 64x64, batch 16 (M = 65536: two rounds of the 256x160 ping-pong tile):
+    conv(a*x + b*y) == a*conv(x) + b*conv(y) up to bf16 rounding of inputs / outputs, and two runs are bit-identical."""
+    from adaface_amd import ops
+    g = torch.Generator(device=gpu).manual_seed(1)
+    x = torch.randn(16, 320, 64, 64, generator=g, device=gpu).bfloat16().float()
+    y = torch.randn(16, 320, 64, 64, generator=g, device=gpu).bfloat16().float()
+    w = (torch.randn(320, 320, 3, 3, generator=g, device=gpu) / math.sqrt(320 * 9)).bfloat16().float()
+    cx = ops.conv2d(x, w, dtype="bf16")
+    assert _last_plan()[0] == 5
+    assert torch.equal(cx, ops.conv2d(x, w, dtype="bf16"))
+    cy = ops.conv2d(y, w, dtype="bf16")
+    z = (2.0 * x - 0.5 * y)                  # exactly representable combinations stay bf16-exact only approximately:
+    cz = ops.conv2d(z, w, dtype="bf16")      # z is re-rounded to bf16 at the boundary, so compare at bf16 tolerance
+    ref = 2.0 * cx - 0.5 * cy
+    _cmp(report, "fullsize conv linearity 320->320@64 B16", cz, ref, "bf16")
+    # one output pixel against a direct fp64 evaluation (zero-padded border pixel and an interior one)
+    for (b, oy, ox) in ((3, 0, 0), (15, 63, 17), (7, 31, 40)):
+        patch = F.pad(x[b:b + 1].double(), (1, 1, 1, 1))[:, :, oy:oy + 3, ox:ox + 3]
+        direct = (patch * w.double()).sum(dim=(1, 2, 3))
+        assert (cx[b, :, oy, ox].double() - direct).abs().max() < 3e-2 * direct.abs().max()
+
+
+def test_fullsize_attention_key_permutation_invariance(gpu, report):
+    """Self-attention at the 64x64 level (N = S = 4096, 8 heads of 40): softmax(q k^T) v does not depend on the order of
+    the keys -- the property the conv-attention path relies on when it moves the subject's keys to the end."""
+    from adaface_amd import ops
+    g = torch.Generator(device=gpu).manual_seed(2)
+    q = torch.randn(2, 4096, 320, generator=g, device=gpu)
+    k = torch.randn(2, 4096, 320, generator=g, device=gpu)
+    v = torch.randn(2, 4096, 320, generator=g, device=gpu)
+    perm = torch.randperm(4096, generator=torch.Generator().manual_seed(3)).to(gpu)
+    a = ops.attention(q, k, v, heads=8, dtype="bf16")
+    b = ops.attention(q, k[:, perm].contiguous(), v[:, perm].contiguous(), heads=8, dtype="bf16")
+    assert torch.equal(a, ops.attention(q, k, v, heads=8, dtype="bf16"))            # deterministic
+    _cmp(report, "fullsize attention key-permutation invariance N4096 d40", b, a, "bf16")
+    rows = a.view(2, 4096, 8, 40)
+    assert torch.isfinite(rows).all()
+    # convexity: every output is a convex combination of the values of its head
+    vmax = v.view(2, 4096, 8, 40).amax(dim=1, keepdim=True)
+    vmin = v.view(2, 4096, 8, 40).amin(dim=1, keepdim=True)
+    assert (rows <= vmax + 0.05).all() and (rows >= vmin - 0.05).all()
+
+
+def test_fullsize_groupnorm_affine_invariance(gpu, report):
+    """GroupNorm(32) at C = 320, 64x64, batch 16: GN(a*x + b) == GN(x) for a > 0 (per-sample statistics)."""
+    from adaface_amd import ops
+    g = torch.Generator(device=gpu).manual_seed(4)
+    x = torch.randn(16, 320, 64, 64, generator=g, device=gpu)
+    w = torch.randn(320, generator=g, device=gpu) * 0.3 + 1.0
+    b = torch.randn(320, generator=g, device=gpu) * 0.2
+    y0 = ops.group_norm(x, w, b, eps=1e-5, silu=True, dtype="f32")
+    y1 = ops.group_norm(3.0 * x + 0.75, w, b, eps=1e-5, silu=True, dtype="f32")
+    assert torch.equal(y0, ops.group_norm(x, w, b, eps=1e-5, silu=True, dtype="f32"))
+    _cmp(report, "fullsize groupnorm affine invariance C320@64 B16", y1, y0, "f32", tol_scale=5.0)
