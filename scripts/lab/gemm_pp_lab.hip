@@ -60,10 +60,11 @@ __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0
 template <int BN, int MODE>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
                                                       bf16* __restrict__ C, int M, int N, int K, int gm,
-                                                      unsigned long long* __restrict__ dbg) {
+                                                      unsigned long long* __restrict__ dbg, int stagger_units = 0) {
   constexpr int BM = 256, BK = 64;
   constexpr bool STAMP = (MODE & 32) != 0;
-  constexpr bool PERSIST = (MODE & 128) != 0;   // workgroups loop over output tiles; the DMA ring runs across tile boundaries
+  constexpr bool PERSIST = (MODE & 128) != 0;
+  constexpr bool STAGGER = (MODE & 256) != 0;   // persistent workgroups start a quarter tile apart (de-synchronises the output bursts)   // workgroups loop over output tiles; the DMA ring runs across tile boundaries
   constexpr int HN = BN / 2;          // columns per wave group
   constexpr int NI = HN / 16;         // 16-wide n tiles per wave
   constexpr int MI = 4;               // 16-high m tiles per wave (64 rows)
@@ -241,6 +242,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const bf16* __restrict__ X
       tile_coords((int)blockIdx.x + i * (int)gridDim.x, ntiles, ntm, ntn, gm, tm_, tn_);
       m0_ = tm_ * BM; n0_ = tn_ * BN;
     };
+    if constexpr (STAGGER) {
+      const int phase = ((int)blockIdx.x >> 3) & 3;                 // blocks b, b+8, ... share an XCD
+      for (int i = 0; i < phase * stagger_units; ++i) __builtin_amdgcn_s_sleep(32);   // 32 x 64 cycles each
+    }
     int st_i = 0, st_kt = 0;          // staging cursor (runs 1-2 K tiles ahead of the compute cursor)
     { int a_, b_; tile_of(0, a_, b_); compute_goff(a_, b_); }
     auto stage_next = [&](int slot_off) {
@@ -426,6 +431,7 @@ static uint16_t f2bf(float f) {
 static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
 static unsigned long long* g_dbg = nullptr;
+static int g_stagger = 0;
 template <int BN, int MODE>
 static double run(const char* name, const bf16* dX, const bf16* dW, bf16* dC, int M, int N, int K, int gm, int iters) {
   if (!g_dbg) CK(hipMalloc(&g_dbg, 128 * 8));
@@ -440,10 +446,10 @@ static double run(const char* name, const bf16* dX, const bf16* dW, bf16* dC, in
   }
   dim3 grid(nblk), block(512);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_pp_kernel<BN, MODE>), grid, block, lds, 0, dX, dW, dC, M, N, K, gm, g_dbg);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_pp_kernel<BN, MODE>), grid, block, lds, 0, dX, dW, dC, M, N, K, gm, g_dbg, g_stagger);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_pp_kernel<BN, MODE>), grid, block, lds, 0, dX, dW, dC, M, N, K, gm, g_dbg);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_pp_kernel<BN, MODE>), grid, block, lds, 0, dX, dW, dC, M, N, K, gm, g_dbg, g_stagger);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1000.0 / iters;
@@ -466,7 +472,7 @@ static double run(const char* name, const bf16* dX, const bf16* dW, bf16* dC, in
 
 int main(int argc, char** argv) {
   struct Shape { int M, N, K; };
-  std::vector<Shape> shapes = {{65536, 320, 2880}, {65536, 960, 320}, {65536, 2560, 320}, {16384, 5120, 640}};
+  std::vector<Shape> shapes = {{65536, 960, 320}, {65536, 2560, 320}, {16384, 5120, 640}, {16384, 1920, 640}, {65536, 320, 2880}};
   size_t maxX = 0, maxW = 0, maxC = 0;
   for (auto& s : shapes) { maxX = std::max(maxX, (size_t)s.M * s.K); maxW = std::max(maxW, (size_t)s.N * s.K); maxC = std::max(maxC, (size_t)s.M * s.N); }
   std::vector<uint16_t> hX(maxX), hW(maxW), hC(maxC);
@@ -498,8 +504,14 @@ int main(int argc, char** argv) {
       }
       printf("    check: max scaled err %.3e, bad %d / 512\n", maxerr, bad);
     };
+    run<160, 2 + 64>("pp256x160 bal LAG", dX, dW, dC, s.M, s.N, s.K, gm, 20); check();
     run<160, 2 + 64 + 128>("pp256x160 bal LAG PERSIST", dX, dW, dC, s.M, s.N, s.K, gm, 20); check();
-    run<160, 2 + 64 + 128 + 32>("pp256x160 bal LAG PERSIST STAMP", dX, dW, dC, s.M, s.N, s.K, gm, 20);
+    for (int su : {1, 2, 3, 5}) {
+      g_stagger = su;
+      char nm[64]; snprintf(nm, sizeof(nm), "PERSIST STAGGER %dx2k", su);
+      run<160, 2 + 64 + 128 + 256>(nm, dX, dW, dC, s.M, s.N, s.K, gm, 20); if (su == 2) check();
+    }
+    g_stagger = 0;
   }
   return 0;
 }
