@@ -1,1 +1,1 @@
-from adaface_amd.ldm.models.autoencoder import AutoencoderKL  # noqa: F401
+from adaface_amd.ldm.models.autoencoder import AutoencoderKL, DiagonalGaussianDistribution  # noqa: F401
