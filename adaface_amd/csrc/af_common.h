@@ -177,6 +177,7 @@ struct ConvGemmParams {
   int splitk;
   void* ws;
   int group_m;            // grouped tile ordering (set by the launcher): M tiles swept per N tile
+  int howo_shift, wo_shift;  // log2(Ho*Wo), log2(Wo) when they are powers of two, else -1 (set by the launcher)
   int dbg_nobarrier;      // diagnostic: skip main-loop barriers (wrong results; measures barrier cost)
 };
 

@@ -527,9 +527,20 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     const int m = m0 + piece * 8 + srow;
     const bool ok = m < p.M && (g == 0 || q < NX1);
     const int mm = ok ? m : 0;
-    const int b = mm / HoWo;
-    const int rem = mm - b * HoWo;
-    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    // (b, oy, ox) of the output pixel: shifts when the map sizes are powers of two (every SD-1.5 / VAE level) -- the
+    // seven integer divisions per lane cost a few thousand cycles per SIMD at the head of a short-K workgroup
+    int b, oy, ox;
+    if (p.howo_shift >= 0 && p.wo_shift >= 0) {
+      b = mm >> p.howo_shift;
+      const int rem = mm & (HoWo - 1);
+      oy = rem >> p.wo_shift;
+      ox = rem & (p.Wo - 1);
+    } else {
+      b = mm / HoWo;
+      const int rem = mm - b * HoWo;
+      oy = rem / p.Wo;
+      ox = rem - oy * p.Wo;
+    }
     unsigned off = (unsigned)((long)b * p.src_batch_stride * 2) + lchunk;
     if constexpr (GATHER) {
       x_yx[q] = ok ? (((oy * p.stride - p.pad) << 16) | ((ox * p.stride - p.pad) & 0xffff)) : (int)0xC0000000;
@@ -729,7 +740,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
       }
       Quad<T> rq[NI], bq[NI];
       if (rowb) {
-        const T* rp = rowb + (long)(m / HoWo) * p.ldrb + cbase;
+        const T* rp = rowb + (long)(p.howo_shift >= 0 ? m >> p.howo_shift : m / HoWo) * p.ldrb + cbase;
 #pragma unroll
         for (int i = 0; i < NI; ++i) if (i < nblk) bq[i].load(rp + i * 16);
       }
@@ -789,7 +800,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
       v[it][4] = b4.x; v[it][5] = b4.y; v[it][6] = b4.z; v[it][7] = b4.w;
       if (slab) continue;
       if (rowb) {
-        const T* rp = rowb + (long)(m / HoWo) * p.ldrb + n;
+        const T* rp = rowb + (long)(p.howo_shift >= 0 ? m >> p.howo_shift : m / HoWo) * p.ldrb + n;
         bq[it][0].load(rp);
         bq[it][1].load(rp + 4);
       }
@@ -1296,6 +1307,11 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   p.splitk = pl.splitk;
   p.ws = ws;
   g_af_last_plan = pl;
+  {
+    auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (v > 0 && (1 << s) == v) ? s : -1; };
+    p.howo_shift = lg2(p.Ho * p.Wo);
+    p.wo_shift = lg2(p.Wo);
+  }
   p.group_m = pl.group_m > 0 ? pl.group_m : 1;
   p.dbg_nobarrier = env_int("AF_DEBUG_NOBARRIER", 0);  // timing diagnostic only: results are WRONG when set
   if (pl.tile >= 4) {   // ping-pong kernel: the field selects the epilogue instead (0 = direct for GEGLU / split-K slabs, 1 = LDS, 2 = direct)
