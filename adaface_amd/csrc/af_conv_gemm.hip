@@ -788,7 +788,8 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
       const int idx = tid + it * 512;
-      const int row = idx / tpr, c8 = (idx - row * tpr) * 8;
+      const int row = geglu ? idx / (BN / 16) : idx / (BN / 8);   // constant divisors: no runtime integer division
+      const int c8 = (idx - row * tpr) * 8;
       const int m = m0 + pass * 128 + row, n = ncol0 + c8;
       const bool ok = it < nitems && m < p.M && n < Nvalid;
       im[it] = ok ? m : -1;
