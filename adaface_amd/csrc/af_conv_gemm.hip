@@ -1303,6 +1303,18 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   }
   if (p.epilogue == AF_EPI_GEGLU && p.N % 64 != 0) { af_set_error_msg("conv_gemm: GEGLU needs N%%64==0"); return -1; }
   if (p.M <= 0 || p.N <= 0) return 0;
+  {
+    // the gathers address activations and weights with 32-bit byte offsets from one buffer base: refuse operands that
+    // do not fit instead of wrapping around silently (SD-1.5 at batch 8 is ~0.25 GB per activation, the VAE ~1.1 GB)
+    const int HoWo = p.Ho * p.Wo > 0 ? p.Ho * p.Wo : 1;
+    const double nb = (double)((p.M + HoWo - 1) / HoWo);
+    const double src_bytes = nb * (double)p.src_batch_stride * sizeof(T), w_bytes = (double)p.Wrows * p.ldw * sizeof(T);
+    if (src_bytes >= 4294967280.0 || w_bytes >= 4294967280.0) {
+      af_set_error_msg("conv_gemm: operand of %.2f GB exceeds the 4 GB range of the 32-bit gather offsets (split the batch)",
+                       (src_bytes > w_bytes ? src_bytes : w_bytes) / 1e9);
+      return -1;
+    }
+  }
   AfGemmPlan pl = plan ? *plan : af_plan_conv_gemm(p, batch, (int)sizeof(T));
   if (pl.splitk > 1 && !ws) pl.splitk = 1;  // no workspace supplied: fall back to one slice
   p.splitk = pl.splitk;
