@@ -82,6 +82,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const bf16* __restrict__ X
   static_assert(XP0 % 4 == 0 && XP1 % 4 == 0 && WP % 4 == 0, "piece split");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
+  unsigned long long t_entry = 0;
+  if constexpr ((MODE & 32) != 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry)::"memory");
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = wid >> 2, wq = wid & 3;
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
@@ -421,6 +423,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const bf16* __restrict__ X
   }
 
   if constexpr (!PERSIST) store_tile(m0, n0);
+  if constexpr (STAMP && !PERSIST) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the output stores have left the wave
+    unsigned long long t_exit;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_exit)::"memory");
+    if (blockIdx.x == 0 && lane == 0) { dbg[80 + wid * 4 + 0] = tbeg - t_entry; dbg[80 + wid * 4 + 1] = ta - tbeg; dbg[80 + wid * 4 + 2] = t_exit - ta; }
+  }
 }
 
 static uint16_t f2bf(float f) {
@@ -463,6 +471,8 @@ static double run(const char* name, const bf16* dX, const bf16* dW, bf16* dC, in
       const double kt = (double)d[7];
       printf("    wave %d per K-tile: load %.0f  bar1 %.0f  mfma %.0f  vmwait %.0f  bar2 %.0f  | total %.0f cyc/tile, clock %.0f MHz\n", w,
              d[0] / kt, d[1] / kt, d[2] / kt, d[3] / kt, d[4] / kt, d[5] / kt, (double)d[5] / (double)d[6] * 100.0);
+      if (!(MODE & 128)) printf("      whole workgroup: prologue %llu  K loop %llu  epilogue (to stores retired) %llu cycles\n",
+                                h[80 + w * 4 + 0], h[80 + w * 4 + 1], h[80 + w * 4 + 2]);
       if (MODE & 128) printf("      epilogue (store + reset) %.0f cyc per K-tile = %.0f per output tile (K-tiles per output tile %d)\n",
                              h[64 + w] / kt, (double)h[64 + w] / kt * (K / 64), K / 64);
     }
@@ -472,7 +482,7 @@ static double run(const char* name, const bf16* dX, const bf16* dW, bf16* dC, in
 
 int main(int argc, char** argv) {
   struct Shape { int M, N, K; };
-  std::vector<Shape> shapes = {{65536, 960, 320}, {65536, 2560, 320}, {16384, 5120, 640}, {16384, 1920, 640}, {65536, 320, 2880}};
+  std::vector<Shape> shapes = {{65536, 960, 320}, {65536, 2560, 320}, {16384, 1920, 640}, {16384, 640, 5760}};
   size_t maxX = 0, maxW = 0, maxC = 0;
   for (auto& s : shapes) { maxX = std::max(maxX, (size_t)s.M * s.K); maxW = std::max(maxW, (size_t)s.N * s.K); maxC = std::max(maxC, (size_t)s.M * s.N); }
   std::vector<uint16_t> hX(maxX), hW(maxW), hC(maxC);
@@ -505,13 +515,7 @@ int main(int argc, char** argv) {
       printf("    check: max scaled err %.3e, bad %d / 512\n", maxerr, bad);
     };
     run<160, 2 + 64>("pp256x160 bal LAG", dX, dW, dC, s.M, s.N, s.K, gm, 20); check();
-    run<160, 2 + 64 + 128>("pp256x160 bal LAG PERSIST", dX, dW, dC, s.M, s.N, s.K, gm, 20); check();
-    for (int su : {1, 2, 3, 5}) {
-      g_stagger = su;
-      char nm[64]; snprintf(nm, sizeof(nm), "PERSIST STAGGER %dx2k", su);
-      run<160, 2 + 64 + 128 + 256>(nm, dX, dW, dC, s.M, s.N, s.K, gm, 20); if (su == 2) check();
-    }
-    g_stagger = 0;
+    run<160, 2 + 64 + 32>("pp256x160 bal LAG STAMP", dX, dW, dC, s.M, s.N, s.K, gm, 20);
   }
   return 0;
 }

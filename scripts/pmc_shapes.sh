@@ -2,8 +2,8 @@
 # usage: scripts/pmc_shapes.sh <only> ; prints per-dispatch FETCH/WRITE (KiB) of conv_gemm kernels for bench_shapes --only <only> --reps 1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/ps_f gpurun_out/ps_w; mkdir -p gpurun_out/ps_f gpurun_out/ps_w
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "conv_gemm_kernel|conv3x3_halo|gemm_wide|attn_kernel" --output-format csv -d gpurun_out/ps_f -- python scripts/bench_shapes.py --only $1 --reps 1 > gpurun_out/ps_f/out.txt 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --kernel-include-regex "conv_gemm_kernel|conv3x3_halo|gemm_wide|attn_kernel" --output-format csv -d gpurun_out/ps_w -- python scripts/bench_shapes.py --only $1 --reps 1 > gpurun_out/ps_w/out.txt 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "conv_gemm_pp_kernel|conv_gemm_kernel|conv3x3_halo|attn_kernel" --output-format csv -d gpurun_out/ps_f -- python scripts/bench_shapes.py --only $1 --reps 1 > gpurun_out/ps_f/out.txt 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --kernel-include-regex "conv_gemm_pp_kernel|conv_gemm_kernel|conv3x3_halo|attn_kernel" --output-format csv -d gpurun_out/ps_w -- python scripts/bench_shapes.py --only $1 --reps 1 > gpurun_out/ps_w/out.txt 2>&1
 python - <<'PY'
 import csv, glob
 def rows(d, c):
