@@ -209,6 +209,46 @@ def main():
     golden["i2i_z0"], golden["i2i_noise"] = z0.numpy(), enc_noise.numpy()
     golden["i2i_z_enc"], golden["i2i_z_dec"] = z_enc.numpy(), z_dec.numpy()
 
+    # ---- per-op / per-module outputs of the reference's own modules.  Weights: every
+    # parameter, in sorted-name order, = randn(shape, seeded generator) * gain -- the tests regenerate them with
+    # tests/golden/opgold.py:seeded_params, so only inputs and outputs are stored. ----
+    from ldm.modules.attention import CrossAttention, FeedForward, SpatialTransformer
+    from ldm.modules.attention import Normalize as AttnNormalize
+    from ldm.modules.diffusionmodules.openaimodel import ResBlock, Upsample, Downsample
+    from ldm.modules.diffusionmodules.util import normalization
+    sys.path.insert(0, str(OUT))
+    from opgold import seeded_params
+    g6 = torch.Generator().manual_seed(606)
+
+    def fill(module, seed):
+        sdm = seeded_params({k: tuple(v.shape) for k, v in module.state_dict().items()}, seed)
+        module.load_state_dict(sdm, strict=True)
+        return module.eval()
+
+    xg = torch.randn(2, 64, 12, 10, generator=g6) * 1.5 + 0.3
+    gn = fill(normalization(64), 1)                                  # GroupNorm32, eps 1e-5 (util.py:202-219)
+    golden["op_gn_x"], golden["op_gn32_silu"] = xg.numpy(), torch.nn.functional.silu(gn(xg)).numpy()
+    golden["op_normalize"] = fill(AttnNormalize(64), 2)(xg).numpy()  # eps 1e-6 (attention.py:71-72)
+    xl = torch.randn(2, 40, 128, generator=g6)
+    golden["op_ln_x"], golden["op_ln"] = xl.numpy(), fill(torch.nn.LayerNorm(128), 3)(xl).numpy()
+    golden["op_ff_geglu"] = fill(FeedForward(128, glu=True), 4)(xl).numpy()          # attention.py:32-59
+    xa = torch.randn(1, 64, 1280, generator=g6)                                      # self: N = 64, 8 heads of 160
+    golden["op_attn_self_x"] = xa.numpy()
+    golden["op_attn_self"] = fill(CrossAttention(1280, heads=8, dim_head=160), 5)(xa).numpy()
+    xq, xc = torch.randn(2, 96, 128, generator=g6), torch.randn(2, 77, 64, generator=g6)   # cross: S = 77
+    golden["op_attn_cross_x"], golden["op_attn_cross_ctx"] = xq.numpy(), xc.numpy()
+    golden["op_attn_cross"] = fill(CrossAttention(128, context_dim=64, heads=4, dim_head=32), 6)(xq, context=xc).numpy()
+    xr, er = torch.randn(2, 64, 12, 10, generator=g6), torch.randn(2, 256, generator=g6)
+    golden["op_res_x"], golden["op_res_emb"] = xr.numpy(), er.numpy()
+    golden["op_resblock_same"] = fill(ResBlock(64, 256, 0.0, out_channels=64, dims=2), 7)(xr, er).numpy()
+    golden["op_resblock_widen"] = fill(ResBlock(64, 256, 0.0, out_channels=128, dims=2), 8)(xr, er).numpy()
+    golden["op_downsample"] = fill(Downsample(64, True, dims=2, out_channels=64), 9)(xr).numpy()   # conv3x3 s2 pad 1
+    golden["op_upsample"] = fill(Upsample(64, True, dims=2, out_channels=64), 10)(xr).numpy()      # nearest x2 + conv3x3
+    st = fill(SpatialTransformer(64, 2, 32, depth=1, context_dim=64), 11)
+    cst = torch.randn(2, 77, 64, generator=g6)
+    golden["op_st_ctx"] = cst.numpy()
+    golden["op_spatial_transformer"] = st(xr, context=lambda: ((cst, cst), None)).numpy()   # layerwise-context callable
+
     # ---- tiny VAE decoder ----
     vcfg = O.TINY_VAE
     vsd = O.synth_state_dict(O.vae_param_shapes(vcfg), seed=12)

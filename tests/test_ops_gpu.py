@@ -355,3 +355,59 @@ def test_fullsize_groupnorm_affine_invariance(gpu, report):
     y1 = ops.group_norm(3.0 * x + 0.75, w, b, eps=1e-5, silu=True, dtype="f32")
     assert torch.equal(y0, ops.group_norm(x, w, b, eps=1e-5, silu=True, dtype="f32"))
     _cmp(report, "fullsize groupnorm affine invariance C320@64 B16", y1, y0, "f32", tol_scale=5.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The same operators against outputs of the REFERENCE's own modules (tests/golden/gen_golden.py imports
+# ldm.modules.attention / openaimodel on CPU; weights are regenerated from tests/golden/opgold.py): SURVEY.md §8c (1).
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_ops_vs_reference_module_goldens(gpu, report, dtype):
+    import sys
+    from pathlib import Path
+    import numpy as np
+    from adaface_amd import ops
+    gold_dir = Path(__file__).resolve().parent / "golden"
+    sys.path.insert(0, str(gold_dir))
+    from opgold import module_params as mp
+    g = dict(np.load(gold_dir / "golden_tiny.npz"))
+    D = lambda t: t.to(gpu)
+    G = lambda k: torch.tensor(g[k])
+
+    def chk(name, got, key, scale=1.0):
+        _cmp(report, f"refmod {name}", got, G(key), dtype, tol_scale=scale)
+
+    w = mp("gn32")
+    chk("GroupNorm32+SiLU", ops.group_norm(D(G("op_gn_x")), D(w["weight"]), D(w["bias"]), eps=1e-5, silu=True, dtype=dtype), "op_gn32_silu")
+    w = mp("normalize")
+    chk("Normalize eps1e-6", ops.group_norm(D(G("op_gn_x")), D(w["weight"]), D(w["bias"]), eps=1e-6, silu=False, dtype=dtype), "op_normalize")
+    w = mp("ln")
+    chk("LayerNorm", ops.layer_norm(D(G("op_ln_x")), D(w["weight"]), D(w["bias"]), dtype=dtype), "op_ln")
+    w = mp("ff")
+    h = ops.linear(D(G("op_ln_x")), D(w["net.0.proj.weight"]), D(w["net.0.proj.bias"]), geglu=True, dtype=dtype)
+    chk("FeedForward GEGLU", ops.linear(h, D(w["net.2.weight"]), D(w["net.2.bias"]), dtype=dtype), "op_ff_geglu", 2.0)
+    w = mp("attn_self")
+    x = D(G("op_attn_self_x"))
+    q, k, v = (ops.linear(x, D(w[f"to_{n}.weight"]), dtype=dtype) for n in "qkv")
+    a = ops.attention(q, k, v, heads=8, dtype=dtype)
+    chk("CrossAttention self N64 dh160", ops.linear(a, D(w["to_out.0.weight"]), D(w["to_out.0.bias"]), dtype=dtype), "op_attn_self", 2.0)
+    w = mp("attn_cross")
+    x, c = D(G("op_attn_cross_x")), D(G("op_attn_cross_ctx"))
+    q = ops.linear(x, D(w["to_q.weight"]), dtype=dtype)
+    k, v = ops.linear(c, D(w["to_k.weight"]), dtype=dtype), ops.linear(c, D(w["to_v.weight"]), dtype=dtype)
+    a = ops.attention(q, k, v, heads=4, dtype=dtype)
+    chk("CrossAttention cross S77", ops.linear(a, D(w["to_out.0.weight"]), D(w["to_out.0.bias"]), dtype=dtype), "op_attn_cross", 2.0)
+    x = D(G("op_res_x"))
+    w = mp("down")
+    chk("Downsample conv3x3 s2", ops.conv2d(x, D(w["op.weight"]), D(w["op.bias"]), stride=2, dtype=dtype), "op_downsample")
+    w = mp("up")
+    chk("Upsample nearest2x+conv3x3", ops.conv2d(x, D(w["conv.weight"]), D(w["conv.bias"]), upsample=True, dtype=dtype), "op_upsample")
+    # ResBlock (openaimodel.py:259-279) assembled from the operator entry points
+    for name, key in (("res_same", "op_resblock_same"), ("res_widen", "op_resblock_widen")):
+        w = mp(name)
+        emb = F.linear(F.silu(G("op_res_emb")), w["emb_layers.1.weight"], w["emb_layers.1.bias"])   # [2, Cout] (tiny, host)
+        h = ops.group_norm(x, D(w["in_layers.0.weight"]), D(w["in_layers.0.bias"]), eps=1e-5, silu=True, dtype=dtype)
+        h = ops.conv2d(h, D(w["in_layers.2.weight"]), D(w["in_layers.2.bias"]), dtype=dtype) + D(emb)[:, :, None, None]
+        h = ops.group_norm(h, D(w["out_layers.0.weight"]), D(w["out_layers.0.bias"]), eps=1e-5, silu=True, dtype=dtype)
+        skip = x if "skip_connection.weight" not in w else ops.conv2d(x, D(w["skip_connection.weight"]), D(w["skip_connection.bias"]), dtype=dtype)
+        chk(f"ResBlock {name}", ops.conv2d(h, D(w["out_layers.3.weight"]), D(w["out_layers.3.bias"]), residual=skip, dtype=dtype), key, 2.0)

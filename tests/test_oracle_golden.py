@@ -181,3 +181,32 @@ def test_sd15_vae_encoder_matches_reference():
     mom = O.vae_encode_moments(sd, cfg, x)
     ref = g["sd15_enc_moments"]
     assert np.abs(mom.numpy() - ref).max() < 5e-5 * np.abs(ref).max()
+
+
+def test_reference_module_goldens(tiny):
+    """outputs of the reference's own GroupNorm32 / Normalize / LayerNorm / FeedForward(GEGLU) /
+    CrossAttention (self N=64 dh=160, cross S=77) / ResBlock / Downsample / Upsample / SpatialTransformer (context
+    passed as the layerwise callable) vs the oracle's functions on the same seeded weights."""
+    import torch.nn.functional as F
+    sys.path.insert(0, str(GOLD))
+    from opgold import module_params as mp
+    T = lambda k: torch.tensor(tiny[k])
+
+    def close(got, key, tol=2e-5):
+        ref = tiny[key]
+        assert got.shape == ref.shape, (key, got.shape, ref.shape)
+        assert np.abs(got.numpy() - ref).max() < tol * np.abs(ref).max(), key
+
+    close(F.silu(O._gn(mp("gn32", "n."), "n", T("op_gn_x"), 1e-5)), "op_gn32_silu")
+    close(O._gn(mp("normalize", "n."), "n", T("op_gn_x"), 1e-6), "op_normalize")
+    close(O._ln(mp("ln", "n."), "n", T("op_ln_x")), "op_ln")
+    close(O.feed_forward(mp("ff", "f."), "f", T("op_ln_x")), "op_ff_geglu")
+    close(O.cross_attention(mp("attn_self", "a."), "a", T("op_attn_self_x"), None, None, 8), "op_attn_self")
+    ctx = T("op_attn_cross_ctx")
+    close(O.cross_attention(mp("attn_cross", "a."), "a", T("op_attn_cross_x"), ctx, ctx, 4), "op_attn_cross")
+    x, emb = T("op_res_x"), T("op_res_emb")
+    close(O.resblock(mp("res_same", "r."), "r", x, emb), "op_resblock_same")
+    close(O.resblock(mp("res_widen", "r."), "r", x, emb), "op_resblock_widen")
+    close(O._conv(mp("down", "d."), "d.op", x, stride=2), "op_downsample")
+    close(O._conv(mp("up", "u."), "u.conv", F.interpolate(x, scale_factor=2, mode="nearest")), "op_upsample")
+    close(O.spatial_transformer(mp("st", "s."), "s", x, T("op_st_ctx"), 2, 1), "op_spatial_transformer")
