@@ -72,6 +72,14 @@ _SIGS = [
     ("af_last_gemm_plan", C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("af_prof_collect", C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]),
+    ("af_unet_num_blocks", C.c_int, [_P]),
+    ("af_unet_block_shape", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("af_unet_set_tap", C.c_int, [_P, C.c_int, _P]),
+    ("af_gemm_plan_counts", C.c_int, [C.POINTER(C.c_int64)]),
+    ("af_gemm_plan_counts_reset", C.c_int, []),
+    ("af_knob_set", C.c_int, [C.c_char_p, C.c_int]),
+    ("af_knob_get", C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    ("af_knob_reset", C.c_int, []),
     ("af_op_conv2d", C.c_int, [C.c_int, _P, _P, _P, _P, _P] + [C.c_int] * 9 + [_P]),
     ("af_op_linear", C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     ("af_op_groupnorm", C.c_int, [C.c_int, _P, _P, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
@@ -102,6 +110,27 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def set_knob(name: str, value: int) -> None:
+    """af_knob_set: force a planner choice / kernel variant (tests, lab scripts)."""
+    check(load().af_knob_set(name.encode(), int(value)), f"af_knob_set({name})")
+
+
+def reset_knobs() -> None:
+    load().af_knob_reset()
+
+
+def plan_counts(reset: bool = False) -> dict:
+    """af_gemm_plan_counts as a dict: tile0..tile5, halo, splitk."""
+    lib = load()
+    c = (C.c_int64 * 8)()
+    check(lib.af_gemm_plan_counts(c), "af_gemm_plan_counts")
+    if reset:
+        lib.af_gemm_plan_counts_reset()
+    out = {f"tile{i}": int(c[i]) for i in range(6)}
+    out["halo"], out["splitk"] = int(c[6]), int(c[7])
+    return out
 
 
 def check(rc: int, what: str = "") -> None:

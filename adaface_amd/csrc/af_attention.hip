@@ -210,15 +210,22 @@ template <typename T, int DH> __device__ __forceinline__ void attn_body(const At
     // tile maximum: four independent max3 chains, then across the two lane halves.  The chain heads read MFMA
     // results from inline asm: hipcc inserts no MFMA-result wait states for an asm statement (cdna guide 5.7 item 2),
     // and a too-early read returns stale registers (seen as run-to-run differences), so they sit behind an s_nop.
+    // Wait states between an MFMA's result write and a VALU read of it that the compiler cannot see (cdna guide 5.7
+    // item 2): 12 for the 8-pass v_mfma_f32_32x32x16_bf16 (s_nop 11 would do; s_nop 15 = 16 states is what ships);
+    // the f32 parity build multiplies with the 16-pass v_mfma_f32_32x32x2_f32, whose result needs 8 more (about 20),
+    // so it takes s_nop 15 + s_nop 7 = 24 states.  The nops are INSIDE the asm statement that reads the registers.
     float mxa, mxb, mxc, mxd;
-    asm("s_nop 15\n\t"
-        "v_max3_f32 %0, %4, %5, %6\n\t"
-        "v_max3_f32 %1, %7, %8, %9\n\t"
-        "v_max3_f32 %2, %10, %11, %12\n\t"
-        "v_max3_f32 %3, %13, %14, %15"
-        : "=&v"(mxa), "=&v"(mxb), "=&v"(mxc), "=&v"(mxd)
-        : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][8]), "v"(s[0][9]), "v"(s[0][10]), "v"(s[1][0]),
-          "v"(s[1][1]), "v"(s[1][2]), "v"(s[1][8]), "v"(s[1][9]), "v"(s[1][10]));
+#define AF_ATTN_MAX_HEADS(NOPS)                                                                                     \
+    asm(NOPS "v_max3_f32 %0, %4, %5, %6\n\t"                                                                        \
+             "v_max3_f32 %1, %7, %8, %9\n\t"                                                                        \
+             "v_max3_f32 %2, %10, %11, %12\n\t"                                                                     \
+             "v_max3_f32 %3, %13, %14, %15"                                                                         \
+        : "=&v"(mxa), "=&v"(mxb), "=&v"(mxc), "=&v"(mxd)                                                            \
+        : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][8]), "v"(s[0][9]), "v"(s[0][10]), "v"(s[1][0]),        \
+          "v"(s[1][1]), "v"(s[1][2]), "v"(s[1][8]), "v"(s[1][9]), "v"(s[1][10]))
+    if constexpr (BF) AF_ATTN_MAX_HEADS("s_nop 15\n\t");
+    else AF_ATTN_MAX_HEADS("s_nop 15\n\ts_nop 7\n\t");
+#undef AF_ATTN_MAX_HEADS
     mxa = max3f(mxa, s[0][3], s[0][4]); mxb = max3f(mxb, s[0][11], s[0][12]);
     mxc = max3f(mxc, s[1][3], s[1][4]); mxd = max3f(mxd, s[1][11], s[1][12]);
     mxa = max3f(mxa, s[0][5], s[0][6]); mxb = max3f(mxb, s[0][13], s[0][14]);
@@ -367,17 +374,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 template <typename T, int DH> static int launch_attn(const AttnParams& p, int B, hipStream_t stream) {
   using C = AttnCfg<T, DH>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<T, DH>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel_w4<T, DH>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0, attr_done_w4 = 0;
+  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&attn_kernel<T, DH>), C::LDS_BYTES)) return rc;
+  if (int rc = af_ensure_dynamic_lds(attr_done_w4, reinterpret_cast<const void*>(&attn_kernel_w4<T, DH>), C::LDS_BYTES)) return rc;
   dim3 grid((p.Nq + 127) / 128, p.H, B);
-  static const int w4 = getenv("AF_ATTN_W4") ? atoi(getenv("AF_ATTN_W4")) : 1;
-  if (C::BF && DH == 40 && w4)
+  if (C::BF && DH == 40 && g_af_knobs.attn_w4)
     hipLaunchKernelGGL((attn_kernel_w4<T, DH>), grid, dim3(256), C::LDS_BYTES, stream, p);
   else
     hipLaunchKernelGGL((attn_kernel<T, DH>), grid, dim3(256), C::LDS_BYTES, stream, p);

@@ -27,8 +27,22 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 void af_set_error_msg(const char* fmt, ...);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): remember per device id where it has
+// been raised (one mask per kernel instantiation; a handle may live on any GPU of the node)
+static inline int af_ensure_dynamic_lds(unsigned long long& done_mask, const void* fn, int bytes) {
+  int dev = 0;
+  HIP_CHECK_RET(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && ((done_mask >> dev) & 1ull)) return 0;
+  HIP_CHECK_RET(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (dev >= 0 && dev < 64) done_mask |= 1ull << dev;
+  return 0;
+}
+
 // per-kernel-class HIP-event profiling (enabled only by bench.py; see af_prof_* in adaface_hip.h)
-enum { AF_K_CONV_GEMM = 0, AF_K_ATTENTION = 1, AF_K_GROUPNORM = 2, AF_K_LAYERNORM = 3, AF_K_OTHER = 4, AF_K_COUNT = 5 };
+// classes 5-7 split the eight-wave ping-pong kernel out of the conv/linear class by instantiation, so that the bench can
+// quote ONE kernel (conv_gemm_pp_kernel<160, true>, the 3x3 convolutions) with its own launch count and duration
+enum { AF_K_CONV_GEMM = 0, AF_K_ATTENTION = 1, AF_K_GROUPNORM = 2, AF_K_LAYERNORM = 3, AF_K_OTHER = 4,
+       AF_K_PP160_GATHER = 5, AF_K_PP160_PLAIN = 6, AF_K_PP128 = 7, AF_K_COUNT = 8 };
 extern int g_af_prof_enabled;
 extern int g_af_prof_stride;              // bracket only every stride-th launch of a class (>= 1)
 extern long g_af_prof_seen[AF_K_COUNT];   // launches seen per class since af_prof_reset
@@ -47,6 +61,26 @@ struct AfProfScope {
     if (on) af_prof_end_impl(s);
   }
 };
+
+// Tuning / diagnostic knobs (planner thresholds, forced tiles).  One plain struct the launchers read: it is filled ONCE
+// from the AF_* environment variables when the library is loaded and afterwards changed only through af_knob_set
+// (tests force a kernel variant that way).  Nothing on the launch path calls getenv, and no knob changes results.
+struct AfKnobs {
+  int splitk_target;        // AF_SPLITK_TARGET        four-wave kernels: workgroups aimed for when slicing K
+  int conv_halo;            // AF_CONV_HALO            0 = never use the LDS-halo 3x3 kernel
+  int gemm_pp;              // AF_GEMM_PP              0 = never use the eight-wave ping-pong kernel
+  int gemm_pp_geglu_minkt;  // AF_GEMM_PP_GEGLU_MINKT  GEGLU on the ping-pong kernel from this many K tiles
+  int gemm_pp_minfill;      // AF_GEMM_PP_MINFILL      ping-pong kernel from this grid fill (percent)
+  int gemm_tile;            // AF_GEMM_TILE            >= 0: force a four-wave tile
+  int gemm_splitk;          // AF_GEMM_SPLITK          >= 1: force the number of K slices
+  int gemm_groupm;          // AF_GEMM_GROUPM          >= 1: force the grouped tile order
+  int gemm_dma;             // AF_GEMM_DMA             0 / 1: force register / LDS-DMA staging in the four-wave kernel
+  int pp_direct;            // AF_PP_DIRECT            0 / 1: force the LDS / direct epilogue of the ping-pong kernel
+  int attn_w4;              // AF_ATTN_W4              0 = dh-40 attention without the four-waves-per-SIMD cap
+  int gn_small;             // AF_GN_SMALL             0 = no single-launch GroupNorm for small maps
+  int gn_fold;              // AF_GN_FOLD              0 = separate GroupNorm finalize pass
+};
+extern AfKnobs g_af_knobs;
 
 // ---------------------------------------------------------------------------
 // scalar conversion helpers
@@ -178,7 +212,8 @@ struct ConvGemmParams {
   void* ws;
   int group_m;            // grouped tile ordering (set by the launcher): M tiles swept per N tile
   int howo_shift, wo_shift;  // log2(Ho*Wo), log2(Wo) when they are powers of two, else -1 (set by the launcher)
-  int dbg_nobarrier;      // diagnostic: skip main-loop barriers (wrong results; measures barrier cost)
+  int pp_epilogue;        // ping-pong kernel (set by the launcher): 0 = direct for GEGLU / split-K slabs and LDS
+                          // otherwise, 1 = always through LDS, 2 = always direct
 };
 
 struct AfGemmPlan {

@@ -720,7 +720,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
   const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
   const T* __restrict__ rowb = reinterpret_cast<const T*>(p.rowbias);
   float* slab = p.splitk > 1 ? reinterpret_cast<float*>(p.ws) + (long)zk * p.M * p.N : nullptr;
-  if (p.dbg_nobarrier == 2 || (p.dbg_nobarrier == 0 && (geglu || slab))) {
+  if (p.pp_epilogue == 2 || (p.pp_epilogue == 0 && (geglu || slab))) {
     // Direct epilogue: every lane stores its 4 consecutive output channels of a pixel straight from the accumulator
     // (8-byte stores, four lanes covering a 32-byte run of the row; fp32 split-K slabs: 16-byte stores).  No LDS pass,
     // no workgroup barriers; the time-bias / residual quads of a row group are fetched before its first store.
@@ -998,10 +998,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
   // end of a step: publish the next weight tile; at a channel-chunk boundary swap in the prefetched halo
   auto step_end = [&]() {
     const bool boundary = (c_tap == 8) && (c_cc + 1 < NC);
-    if (!p.dbg_nobarrier) __syncthreads();
+    __syncthreads();
     if (boundary) {
       hstore();
-      if (!p.dbg_nobarrier) __syncthreads();
+      __syncthreads();
     }
     if (++c_tap == 9) { c_tap = 0; ++c_cc; }
   };
@@ -1108,11 +1108,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvGemmParams
 // planning (tile shape + split-K) and launch
 // ---------------------------------------------------------------------------
 AfGemmPlan g_af_last_plan = {0, 1, 0, 0, 1};
+// launches since af_gemm_plan_counts_reset: [0..5] by tile (implicit-GEMM / ping-pong kernels), [6] LDS-halo kernel,
+// [7] launches that sliced K (counted in their tile's slot as well)
+long g_af_plan_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-static int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return s ? atoi(s) : dflt;
-}
 
 // tile: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64
 AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) {
@@ -1139,7 +1138,7 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
   const long nb = (long)((p.M + bm[pl.tile] - 1) / bm[pl.tile]) * ((p.N + bn[pl.tile] - 1) / bn[pl.tile]) * batch;
   if (batch == 1 && !geglu && nb < 256 && KT >= 16) {
     // deep-K, few tiles: slice K so that ~2 blocks per CU exist, each slice >= 8 K tiles
-    const int target = env_int("AF_SPLITK_TARGET", 320);
+    const int target = g_af_knobs.splitk_target;
     int s = (int)((target + nb - 1) / nb);
     if (s > KT / 8) s = KT / 8;
     if (s > 16) s = 16;
@@ -1156,7 +1155,7 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
   // 3x3 / stride 1 / no upsample on maps that tile by 4x32 or 8x16 pixels: LDS-halo kernel (tile 2 or 0 = BN 64 / 128)
   pl.halo_tw = 0;
   if (p.ks == 3 && p.stride == 1 && p.up == 0 && p.pad == 1 && batch == 1 && !geglu && pl.splitk == 1 &&
-      p.Ho == p.Hi && p.Wo == p.Wi && p.ldc >= p.Cin && env_int("AF_CONV_HALO", 1)) {
+      p.Ho == p.Hi && p.Wo == p.Wi && p.ldc >= p.Cin && g_af_knobs.conv_halo) {
     if (p.Wo % 32 == 0 && p.Ho % 4 == 0) pl.halo_tw = 32;
     else if (p.Wo % 16 == 0 && p.Ho % 8 == 0) pl.halo_tw = 16;
     if (pl.halo_tw) {
@@ -1168,14 +1167,14 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
   }
   // ping-pong 256 x {160,128} tiles (bf16): preferred wherever the grid fills the chip.  tile 5 = BN 160 (divides
   // every SD-1.5 channel count), tile 4 = BN 128 (GEGLU needs an even number of 16-column blocks per wave; VAE widths)
-  if (elem_size == 2 && batch == 1 && p.K % 64 == 0 && p.Cin % 64 == 0 && env_int("AF_GEMM_PP", 1)) {
+  if (elem_size == 2 && batch == 1 && p.K % 64 == 0 && p.Cin % 64 == 0 && g_af_knobs.gemm_pp) {
     int cand = -1;
     if (!geglu && p.N % 160 == 0) cand = 5;
     else if (p.N % 128 == 0) cand = 4;
     // (GEGLU with few K tiles is bound by its epilogue -- ~6k VALU cycles of erf per SIMD against 7.5k cycles of main
     // loop at K = 320 -- which one workgroup per CU cannot overlap with another tile's MFMAs; with the register-phase
     // epilogue it still measures 10-18 % ahead of the four-wave kernel, so the threshold defaults to 0)
-    if (geglu && KT < env_int("AF_GEMM_PP_GEGLU_MINKT", 0)) cand = -1;
+    if (geglu && KT < g_af_knobs.gemm_pp_geglu_minkt) cand = -1;
     if (cand >= 0) {
       const int tbn = cand == 5 ? 160 : 128;
       const long nb = (long)((p.M + 255) / 256) * (p.N / tbn);
@@ -1190,16 +1189,16 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
       }
       const long nbs = nb * s;
       const double fill = (double)nbs / (double)(((nbs + 255) / 256) * 256);
-      if (fill >= env_int("AF_GEMM_PP_MINFILL", 50) * 0.01 && p.M >= 512) {
+      if (fill >= g_af_knobs.gemm_pp_minfill * 0.01 && p.M >= 512) {
         pl.tile = cand;
         pl.splitk = s;
         pl.halo_tw = 0;
       }
     }
   }
-  const int ft = env_int("AF_GEMM_TILE", -1);
+  const int ft = g_af_knobs.gemm_tile;
   if (ft >= 0 && ft < 4 && !(geglu && bn[ft] != 128)) pl.tile = ft;
-  const int fs = env_int("AF_GEMM_SPLITK", -1);
+  const int fs = g_af_knobs.gemm_splitk;
   if (fs >= 1 && batch == 1 && !geglu) pl.splitk = fs > KT ? KT : fs;
   if (pl.splitk > 1) pl.halo_tw = 0;
   if (pl.splitk > 1) pl.ws_bytes = (size_t)pl.splitk * p.M * p.N * sizeof(float);
@@ -1222,8 +1221,7 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
       const double c = xb * ((double)NT / gn_eff) + wb * ((double)MT / gm_eff);
       if (c < bestc * 0.999) { bestc = c; bestg = gmm; }
     }
-    pl.group_m = env_int("AF_GEMM_GROUPM", bestg);
-    if (pl.group_m < 1) pl.group_m = 1;
+    pl.group_m = g_af_knobs.gemm_groupm >= 1 ? g_af_knobs.gemm_groupm : bestg;
   }
   return pl;
 }
@@ -1231,12 +1229,8 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
 template <typename T, int BM, int BN, bool DMA>
 static int launch_cfg2(const ConvGemmParams& p, int batch, hipStream_t stream) {
   using C = TileCfg<BM, BN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, DMA>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;
+  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, DMA>), C::LDS_BYTES)) return rc;
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, 1, p.splitk > 1 ? p.splitk : batch);
   hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, DMA>), grid, dim3(256), C::LDS_BYTES, stream, p);
@@ -1247,7 +1241,7 @@ template <typename T, int BM, int BN>
 static int launch_cfg(const ConvGemmParams& p, int batch, hipStream_t stream) {
   // LDS-DMA staging wins on deep-K problems (fewer VGPRs, no ds_write); with few K tiles the 2-deep register
   // prefetch hides the first loads better.  AF_GEMM_DMA = 0 / 1 forces one variant, default: by K depth.
-  static const int force = env_int("AF_GEMM_DMA", -1);
+  const int force = g_af_knobs.gemm_dma;
   const int kt_per_slice = p.K / (128 / (int)sizeof(T)) / (p.splitk > 1 ? p.splitk : 1);
   const bool use_dma = force >= 0 ? force != 0 : kt_per_slice >= 32;
   return use_dma ? launch_cfg2<T, BM, BN, true>(p, batch, stream) : launch_cfg2<T, BM, BN, false>(p, batch, stream);
@@ -1256,14 +1250,9 @@ static int launch_cfg(const ConvGemmParams& p, int batch, hipStream_t stream) {
 template <int BN> static int launch_pp(const ConvGemmParams& p, hipStream_t stream) {
   using C = PpCfg<BN>;
   const bool gather = !(p.ks == 1 && p.pad == 0);
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    attr_set = true;
-  }
+  static unsigned long long attr_done_g = 0, attr_done_p = 0;
+  if (int rc = af_ensure_dynamic_lds(attr_done_g, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, true>), C::LDS_BYTES)) return rc;
+  if (int rc = af_ensure_dynamic_lds(attr_done_p, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, false>), C::LDS_BYTES)) return rc;
   dim3 grid(((p.M + 255) / 256) * (p.N / BN), 1, p.splitk > 1 ? p.splitk : 1);
   if (gather) hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, true>), grid, dim3(512), C::LDS_BYTES, stream, p);
   else hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, false>), grid, dim3(512), C::LDS_BYTES, stream, p);
@@ -1273,12 +1262,8 @@ template <int BN> static int launch_pp(const ConvGemmParams& p, hipStream_t stre
 
 template <typename T, int TW, int BN> static int launch_halo(const ConvGemmParams& p, hipStream_t stream) {
   using C = HaloCfg<TW, BN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, TW, BN>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;
+  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, TW, BN>), C::LDS_BYTES)) return rc;
   dim3 grid((p.M / 128) * ((p.N + BN - 1) / BN), 1, 1);
   hipLaunchKernelGGL((conv3x3_halo_kernel<T, TW, BN>), grid, dim3(256), C::LDS_BYTES, stream, p);
   HIP_CHECK_RET(hipGetLastError());
@@ -1320,18 +1305,18 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   p.splitk = pl.splitk;
   p.ws = ws;
   g_af_last_plan = pl;
+  g_af_plan_counts[pl.halo_tw ? 6 : (pl.tile >= 0 && pl.tile < 6 ? pl.tile : 0)] += 1;
+  if (pl.splitk > 1) g_af_plan_counts[7] += 1;
   {
     auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (v > 0 && (1 << s) == v) ? s : -1; };
     p.howo_shift = lg2(p.Ho * p.Wo);
     p.wo_shift = lg2(p.Wo);
   }
   p.group_m = pl.group_m > 0 ? pl.group_m : 1;
-  p.dbg_nobarrier = env_int("AF_DEBUG_NOBARRIER", 0);  // timing diagnostic only: results are WRONG when set
-  if (pl.tile >= 4) {   // ping-pong kernel: the field selects the epilogue instead (0 = direct for GEGLU / split-K slabs, 1 = LDS, 2 = direct)
-    static const int pp_direct = env_int("AF_PP_DIRECT", -1);
-    p.dbg_nobarrier = pp_direct < 0 ? 0 : (pp_direct ? 2 : 1);
-  }
-  AfProfScope prof(AF_K_CONV_GEMM, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K) * batch,
+  p.pp_epilogue = g_af_knobs.pp_direct < 0 ? 0 : (g_af_knobs.pp_direct ? 2 : 1);
+  const int prof_cls = pl.tile == 5 ? ((p.ks == 1 && p.pad == 0) ? AF_K_PP160_PLAIN : AF_K_PP160_GATHER)
+                                     : (pl.tile == 4 ? AF_K_PP128 : AF_K_CONV_GEMM);
+  AfProfScope prof(prof_cls, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K) * batch,
                    ((double)p.M * p.K / (p.ks * p.ks) + (double)p.N * p.K + (double)p.M * p.N) * batch * sizeof(T));
   int rc;
   if (pl.halo_tw) {

@@ -58,3 +58,4 @@ int af_launch_permute_bias(const float* src, float* dst, int rows, int perm, hip
 
 // plan of the most recent af_launch_conv_gemm (diagnostics, af_last_gemm_plan)
 extern AfGemmPlan g_af_last_plan;
+extern long g_af_plan_counts[8];

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <map>
@@ -39,11 +40,38 @@ void af_set_error_msg(const char* fmt, ...) {
   va_end(ap);
 }
 // ----------------------------------------------------------------------------
+// tuning knobs: read from the environment ONCE, when the library is loaded; af_knob_set changes them afterwards
+// ----------------------------------------------------------------------------
+static int knob_env(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+AfKnobs g_af_knobs = {
+    knob_env("AF_SPLITK_TARGET", 320), knob_env("AF_CONV_HALO", 1),       knob_env("AF_GEMM_PP", 1),
+    knob_env("AF_GEMM_PP_GEGLU_MINKT", 0), knob_env("AF_GEMM_PP_MINFILL", 50), knob_env("AF_GEMM_TILE", -1),
+    knob_env("AF_GEMM_SPLITK", -1),    knob_env("AF_GEMM_GROUPM", -1),    knob_env("AF_GEMM_DMA", -1),
+    knob_env("AF_PP_DIRECT", -1),      knob_env("AF_ATTN_W4", 1),         knob_env("AF_GN_SMALL", 1),
+    knob_env("AF_GN_FOLD", 1)};
+static const AfKnobs g_af_knobs_initial = g_af_knobs;
+static int* knob_slot(const char* name) {
+  static const struct { const char* n; int AfKnobs::*m; } tab[] = {
+      {"splitk_target", &AfKnobs::splitk_target}, {"conv_halo", &AfKnobs::conv_halo}, {"gemm_pp", &AfKnobs::gemm_pp},
+      {"gemm_pp_geglu_minkt", &AfKnobs::gemm_pp_geglu_minkt}, {"gemm_pp_minfill", &AfKnobs::gemm_pp_minfill},
+      {"gemm_tile", &AfKnobs::gemm_tile}, {"gemm_splitk", &AfKnobs::gemm_splitk}, {"gemm_groupm", &AfKnobs::gemm_groupm},
+      {"gemm_dma", &AfKnobs::gemm_dma}, {"pp_direct", &AfKnobs::pp_direct}, {"attn_w4", &AfKnobs::attn_w4},
+      {"gn_small", &AfKnobs::gn_small}, {"gn_fold", &AfKnobs::gn_fold}};
+  if (!name) return nullptr;
+  for (auto& t : tab)
+    if (strcmp(t.n, name) == 0) return &(g_af_knobs.*(t.m));
+  return nullptr;
+}
+
+// ----------------------------------------------------------------------------
 // HIP-event profiling per kernel class (bench.py's roofline leg)
 // ----------------------------------------------------------------------------
 int g_af_prof_enabled = 0;
 int g_af_prof_stride = 1;
-long g_af_prof_seen[AF_K_COUNT] = {0, 0, 0, 0, 0};
+long g_af_prof_seen[AF_K_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
 namespace {
 struct ProfRec {
   hipEvent_t start, stop;
@@ -221,6 +249,10 @@ struct af_handle {
   std::vector<int> conv_tokens;   // [conv_batch.size()][9]
   int* ctx_rowmap = nullptr;      // device row map used by set_context when conv attention is on
   size_t ctx_rowmap_n = 0;
+
+  // diagnostic tap (af_unet_set_tap): block whose output the next forwards also write, fp32 NCHW
+  int tap_index = -1;
+  float* tap_out = nullptr;
 
   // runtime state
   Arena arena;
@@ -967,6 +999,12 @@ static int unet_forward_impl(af_handle* h, hipStream_t s, const float* x_dev, co
     return v;  // ld stays the full row length
   };
 
+  // block outputs in forward order: input_blocks 0..n_in-1, middle_block = n_in, output_blocks = n_in + 1 + j
+  auto tap = [&](int idx, const Act& a) -> int {
+    if (R.dry || idx != h->tap_index || !h->tap_out) return 0;
+    return DISPATCH(dt, af_launch_nhwc_to_nchw<bf16>(a.p, h->tap_out, a.B, a.C, a.H * a.W, a.ld, s),
+                    af_launch_nhwc_to_nchw<float>(a.p, h->tap_out, a.B, a.C, a.H * a.W, a.ld, s));
+  };
   Act hcur = x;
   for (int i = 0; i < n_in; ++i) {
     const int j = n_in - 1 - i;  // the output block that will consume this skip
@@ -978,12 +1016,14 @@ static int unet_forward_impl(af_handle* h, hipStream_t s, const float* x_dev, co
       AF_TRY(run_block(h->input_blocks[i], hcur, o, nullptr));
     }
     hcur = o;
+    AF_TRY(tap(i, hcur));
   }
   {
     Act o;
     const Act dst = view(cat[0], 0, ch_h[0]);
     AF_TRY(run_block(h->middle_block, hcur, o, n_out > 0 ? &dst : nullptr));
     hcur = o;
+    AF_TRY(tap(n_in, hcur));
   }
   for (int j = 0; j < n_out; ++j) {
     Act o;
@@ -994,6 +1034,7 @@ static int unet_forward_impl(af_handle* h, hipStream_t s, const float* x_dev, co
       AF_TRY(run_block(h->output_blocks[j], cat[j], o, nullptr));
     }
     hcur = o;
+    AF_TRY(tap(n_in + 1 + j, hcur));
   }
   // out: GroupNorm32 -> SiLU -> conv3x3 (openaimodel.py:693-697)
   Act g = R.alloc_act(Bf, hcur.H, hcur.W, hcur.C);
@@ -1424,6 +1465,42 @@ int af_unet_forward(af_handle* h, const float* x_dev, const int64_t* t_dev, floa
   return unet_forward_impl(h, s, x_dev, t_dev, eps_dev, Bf, H, W);
 }
 
+int af_unet_num_blocks(af_handle* h) {
+  return (h && h->cfg.build_unet) ? (int)(h->input_blocks.size() + 1 + h->output_blocks.size()) : 0;
+}
+
+int af_unet_block_shape(af_handle* h, int block, int H, int W, int* C_out, int* H_out, int* W_out) {
+  if (!h || !h->cfg.build_unet || block < 0 || block >= af_unet_num_blocks(h) || !C_out || !H_out || !W_out) {
+    af_set_error_msg("af_unet_block_shape: bad argument");
+    return AF_ERR_INVALID;
+  }
+  int C = h->cfg.in_channels, idx = 0;
+  auto walk = [&](const UBlock& ub, int skipC) {
+    C += skipC;
+    for (auto& l : ub.layers) {
+      if (l.kind == L_CONV_IN) C = h->cfg.model_channels;
+      else if (l.kind == L_RES) C = h->res[l.idx].cout;
+      else if (l.kind == L_DOWN) { H /= 2; W /= 2; }
+      else if (l.kind == L_UP) { H *= 2; W *= 2; }
+    }
+  };
+  for (auto& ub : h->input_blocks) { walk(ub, 0); if (idx++ == block) goto done; }
+  walk(h->middle_block, 0);
+  if (idx++ == block) goto done;
+  for (auto& ub : h->output_blocks) { walk(ub, 0); if (idx++ == block) goto done; }
+done:
+  *C_out = C; *H_out = H; *W_out = W;
+  return AF_OK;
+}
+
+int af_unet_set_tap(af_handle* h, int block, float* out_dev) {
+  if (!h) { af_set_error_msg("af_unet_set_tap: null handle"); return AF_ERR_INVALID; }
+  if (block >= af_unet_num_blocks(h)) { af_set_error_msg("af_unet_set_tap: block %d out of range", block); return AF_ERR_INVALID; }
+  h->tap_index = (block >= 0 && out_dev) ? block : -1;
+  h->tap_out = h->tap_index >= 0 ? out_dev : nullptr;
+  return AF_OK;
+}
+
 int af_ddim_step(const float* x_dev, const float* eps_cond_dev, const float* eps_uncond_dev, const float* noise_dev,
                  int64_t n, float guidance, float a_t, float a_prev, float sqrt_one_minus_at, float sigma_t,
                  float temperature, float* x_prev_dev, float* pred_x0_dev, void* stream) {
@@ -1486,6 +1563,23 @@ int af_to_uint8(const float* img_dev, uint8_t* u8_dev, int B, int H, int W, void
 
 int64_t af_arena_bytes(af_handle* h) { return h ? (int64_t)h->arena.cap : 0; }
 
+int af_knob_set(const char* name, int value) {
+  int* k = knob_slot(name);
+  if (!k) { af_set_error_msg("af_knob_set: unknown knob '%s'", name ? name : "(null)"); return AF_ERR_NAME; }
+  *k = value;
+  return AF_OK;
+}
+int af_knob_get(const char* name, int* value) {
+  int* k = knob_slot(name);
+  if (!k || !value) { af_set_error_msg("af_knob_get: unknown knob '%s'", name ? name : "(null)"); return AF_ERR_NAME; }
+  *value = *k;
+  return AF_OK;
+}
+int af_knob_reset(void) {
+  g_af_knobs = g_af_knobs_initial;
+  return AF_OK;
+}
+
 int af_prof_enable(int class_mask) {
   g_af_prof_enabled = class_mask;
   return 0;
@@ -1505,6 +1599,15 @@ int af_last_gemm_plan(int* tile, int* splitk, int* halo_tw) {
   if (tile) *tile = g_af_last_plan.tile;
   if (splitk) *splitk = g_af_last_plan.splitk;
   if (halo_tw) *halo_tw = g_af_last_plan.halo_tw;
+  return AF_OK;
+}
+int af_gemm_plan_counts(int64_t* counts8) {
+  if (!counts8) { af_set_error_msg("af_gemm_plan_counts: null argument"); return AF_ERR_INVALID; }
+  for (int i = 0; i < 8; ++i) counts8[i] = g_af_plan_counts[i];
+  return AF_OK;
+}
+int af_gemm_plan_counts_reset(void) {
+  for (int i = 0; i < 8; ++i) g_af_plan_counts[i] = 0;
   return AF_OK;
 }
 int af_prof_collect(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes) {

@@ -435,7 +435,7 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
   {
     // small maps: single-launch register-resident kernel (group channels must be whole 16-byte vectors)
     const int cpg = Cn / GN_GROUPS;
-    static const bool small_ok = !(getenv("AF_GN_SMALL") && atoi(getenv("AF_GN_SMALL")) == 0);
+    const bool small_ok = g_af_knobs.gn_small != 0;
     if (small_ok && cpg % EPC == 0 && (long)HW * (cpg / EPC) <= 256 * GNS_MAXV && Cn % 4 == 0) {
       hipLaunchKernelGGL((gn_small_kernel<T>), dim3(GN_GROUPS, B), dim3(256), 0, stream, reinterpret_cast<const T*>(x),
                          x_bs, ldx, HW, Cn, gamma, beta, eps, silu, reinterpret_cast<T*>(y), y_bs, ldy);
@@ -450,7 +450,7 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
   hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nchunk, B), dim3(256), 0, stream,
                      reinterpret_cast<const T*>(x), x_bs, ldx, HW, Cn, P, partial, nchunk);
   const double count = (double)HW * (double)(Cn / GN_GROUPS);
-  static const bool fold_ok = !(getenv("AF_GN_FOLD") && atoi(getenv("AF_GN_FOLD")) == 0);
+  const bool fold_ok = g_af_knobs.gn_fold != 0;
   const bool fold = fold_ok && nchunk <= 64;  // few chunks: the apply blocks finalize the statistics themselves
   if (!fold) hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, partial, nchunk, count, eps, stats);
   hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nchunk, B), dim3(256), 0, stream,

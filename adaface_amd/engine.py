@@ -153,6 +153,25 @@ class Engine:
         check(self._lib.af_unet_forward(self._h, ptr(x), ptr(t), ptr(out), Bf, H, W, stream_ptr()), "af_unet_forward")
         return out
 
+    def unet_block_outputs(self, x: torch.Tensor, t: torch.Tensor, blocks=None) -> Dict[int, torch.Tensor]:
+        """Outputs of U-Net blocks (forward order: input_blocks, middle_block, output_blocks) as fp32 NCHW tensors, one
+        forward per requested block through the diagnostic tap (af_unet_set_tap).  Parity tests only."""
+        x = x.contiguous().float()
+        Bf, _, H, W = x.shape
+        n = self._lib.af_unet_num_blocks(self._h)
+        out = {}
+        c, hh, ww = C.c_int(), C.c_int(), C.c_int()
+        for b in (range(n) if blocks is None else blocks):
+            check(self._lib.af_unet_block_shape(self._h, b, H, W, C.byref(c), C.byref(hh), C.byref(ww)), "af_unet_block_shape")
+            buf = torch.empty(Bf, c.value, hh.value, ww.value, device=x.device, dtype=torch.float32)
+            check(self._lib.af_unet_set_tap(self._h, b, ptr(buf)), "af_unet_set_tap")
+            try:
+                self.unet_forward(x, t)
+            finally:
+                self._lib.af_unet_set_tap(self._h, -1, None)
+            out[b] = buf
+        return out
+
     def vae_decode(self, z: torch.Tensor, scale_factor: float = 1.0, want_uint8: bool = False, want_float: bool = True):
         z = z.contiguous().float()
         B, _, H, W = z.shape

@@ -12,7 +12,8 @@ from adaface_amd.ldm._hipmodule import HipModule, build_param_tree
 
 class DiagonalGaussianDistribution:
     """ldm/modules/distributions/distributions.py:24-62 (the members the inference path reads).  `sample()` draws its
-    noise with torch.randn on the parameters' device, like the reference; the arithmetic is af_posterior_sample."""
+    noise like the reference does — torch.randn on the HOST generator, then moved to the parameters' device
+    (distributions.py:36) — so a seeded init-image latent matches the reference's; the arithmetic is af_posterior_sample."""
 
     def __init__(self, parameters, deterministic=False, engine=None):
         self.parameters = parameters
@@ -31,7 +32,7 @@ class DiagonalGaussianDistribution:
 
     def sample(self, noise=None, scale: float = 1.0):
         if noise is None and not self.deterministic:
-            noise = torch.randn(self.mean.shape, device=self.parameters.device)
+            noise = torch.randn(self.mean.shape).to(device=self.parameters.device)
         return self._engine.posterior_sample(self.parameters, None if self.deterministic else noise, scale)
 
     def mode(self):

@@ -10,7 +10,8 @@ import numpy as np
 import torch
 
 from adaface_amd import ops
-from adaface_amd.ldm.modules.diffusionmodules.util import make_ddim_sampling_parameters, make_ddim_timesteps
+from adaface_amd.ldm.modules.diffusionmodules.util import (make_ddim_sampling_parameters, make_ddim_timesteps,
+                                                            noise_like)
 
 
 class PLMSSampler(object):
@@ -136,8 +137,15 @@ class PLMSSampler(object):
             return ops.lincomb([(e[b:], unconditional_guidance_scale), (e[:b], 0.0)], cfg=True)  # e_u + g (e_c - e_u)
 
         def get_x_prev_and_pred_x0(e, idx):
+            # one noise_like draw per call, as the reference (plms.py:236), so the device generator advances
+            # identically even when sigma_t = 0 (eta = 0) makes the term vanish
+            sigma_t = f32(self.ddim_sigmas[idx])
+            noise = noise_like(x.shape, x.device, repeat_noise)
+            if noise_dropout > 0.:
+                noise = torch.nn.functional.dropout(noise, p=noise_dropout)
             return ops.ddim_step(x, e, None, 1.0, f32(self.ddim_alphas[idx]), f32(self.ddim_alphas_prev[idx]),
-                                 f32(self.ddim_sqrt_one_minus_alphas[idx]), f32(self.ddim_sigmas[idx]))
+                                 f32(self.ddim_sqrt_one_minus_alphas[idx]), sigma_t,
+                                 None if sigma_t == 0. else noise, temperature)
 
         e_t = get_model_output(x, t)
         if len(old_eps) == 0:        # pseudo improved Euler (2nd order)

@@ -9,10 +9,66 @@ The reference has no equivalent — it is single-process, single-GPU (scripts/st
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+import os
+import socket
+import subprocess
+import sys
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launched_by_torchrun() -> bool:
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+
+
+def launch_ranks(n_ranks: int, script: str, argv: Sequence[str], env: Optional[dict] = None) -> int:
+    """Start `script argv...` as n_ranks FRESH processes (one per GPU) under torch.distributed.run on 127.0.0.1 and
+    return its exit code.  Must be called before the calling process has touched the GPU: the ranks are children of
+    the elastic launcher, which is a child of ours — no process that initialised HIP is ever replaced by another
+    program.  `python bench.py --gpus N` and `scripts/stable_txt2img.py --gpus N` use this when they were not
+    themselves started by a launcher (no WORLD_SIZE / RANK in the environment)."""
+    if n_ranks < 2:
+        raise ValueError("launch_ranks is for n_ranks >= 2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, *argv]
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL cannot exchange buffer handles without it here
+    return subprocess.run(cmd, env=e).returncode
+
+
+def init_distributed(expected_world: int, backend: str = "nccl", device: Optional[torch.device] = None) -> Tuple[int, int]:
+    """Join the process group torch.distributed.run prepared (env://) and CHECK it: returns (rank, world) where world is
+    the number of ranks the backend actually connected; raises SystemExit if that differs from `expected_world` or,
+    for "nccl" (= RCCL on ROCm), if two ranks share a device.  world == 1 with no launcher: no process group."""
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != expected_world:
+        raise SystemExit(f"--gpus {expected_world} but the launcher started WORLD_SIZE={world_env} ranks")
+    if world_env == 1 and not launched_by_torchrun():
+        return 0, 1
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        dist.init_process_group(backend)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    # one all-reduce proves every rank is reachable through the backend (and, on GPUs, over xGMI)
+    dev = device if backend == "nccl" else torch.device("cpu")
+    probe = torch.zeros(world, dtype=torch.int64, device=dev)
+    probe[rank] = 1 + (device.index if (backend == "nccl" and device is not None and device.index is not None) else rank)
+    dist.all_reduce(probe)
+    seen = probe.cpu().tolist()
+    if world != expected_world or any(v == 0 for v in seen):
+        raise SystemExit(f"process group has {world} ranks ({seen}), --gpus asked for {expected_world}")
+    if backend == "nccl" and len(set(seen)) != world:
+        raise SystemExit(f"ranks share a device: local device ids {seen}")
+    return rank, world
 
 
 def world() -> Tuple[int, int]:

@@ -40,3 +40,17 @@ def synth_context(batch: int, seed: int, device, n_layers: int = 16, n_tokens: i
         base = base.expand(batch, 1, n_tokens, dim)
     ctx = base.expand(batch, n_layers, n_tokens, dim).reshape(batch * n_layers, n_tokens, dim).contiguous()
     return ctx.to(device)
+
+
+def synth_context_adaprompt(batch: int, seed: int, device, n_layers: int = 16, n_tokens: int = 77, dim: int = 768,
+                            subj_start: int = 6, n_subj_vectors: int = 16, subj_std: float = 0.07) -> torch.Tensor:
+    """BASELINE.json configs[2] ("AdaPrompt embedding injected into the 77-token context") as synthetic data, SURVEY.md
+    §8(d): a plain-prompt context whose 16 layer copies are identical per sample, with rows subj_start ..
+    subj_start + 15 (the 16 subject vectors, --num_vectors_per_subj_token 16, stable_txt2img.py:258-260) of EVERY layer
+    copy overwritten by per-layer draws of std ~0.07 (embedding_manager.py:1529) — so the 16 layer slices of a sample
+    differ exactly where an AdaFace checkpoint would make them differ.  The real embeddings_gs-4500.pt is not in the
+    tree; shapes, placement and scale follow the reference, the values are synthetic."""
+    ctx = synth_context(batch, seed, "cpu", n_layers, n_tokens, dim).reshape(batch, n_layers, n_tokens, dim).clone()
+    g = torch.Generator(device="cpu").manual_seed(seed + 7919)
+    ctx[:, :, subj_start:subj_start + n_subj_vectors] = torch.randn(batch, n_layers, n_subj_vectors, dim, generator=g) * subj_std
+    return ctx.reshape(batch * n_layers, n_tokens, dim).contiguous().to(device)

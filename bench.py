@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: 512x512 images/sec @ 50 DDIM steps, batch 8 per GPU (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config1|config2|config3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -9,8 +9,21 @@ One "step" = one pass of the hot path over one batch: DDIMSampler.sample (50 ste
 at Bf=16 on 4x64x64 latents with a [256,77,768] layerwise context) + decode_first_stage to 8 uint8 512x512
 frames, through the drop-in classes (ldm.models.diffusion.ddim.DDIMSampler, LatentDiffusion.apply_model,
 AutoencoderKL.decode) and the C ABI underneath.  Inputs are resident in HBM before the timed region.
-Multi-GPU: independent samples, batch 8 per rank (weak scaling), ONE RCCL all-gather of the decoded uint8
-frames per step.  Synthetic data and seeded random-init weights of the SD-1.5 architecture.
+
+Multi-GPU: independent samples, one process per GPU, ONE RCCL all-gather of the decoded uint8 frames
+per step.  `--gpus N` without a launcher (no WORLD_SIZE / RANK in the environment) starts the N ranks itself, as
+fresh child processes under torch.distributed.run, before this process has touched the GPU; the JSON line's
+`n_gpus` is the number of ranks the process group actually connected, and the run fails if that is not N.
+
+Workloads (BASELINE.json `configs`, 0-based):
+  config1 (default)  SD v1.5 512x512, 50 steps, batch 8 per GPU, plain-prompt context (16 identical layer copies)
+  config2            the same with the AdaPrompt subject vectors injected: rows 6..21 of every layer copy differ
+  config3            global batch 64 in micro-batches of 8 per forward, sharded over the ranks (strong scaling)
+Synthetic data and seeded random-init weights of the SD-1.5 architecture (no checkpoint exists offline).
+
+--plumbing-test replaces the HIP path by a stub and the backend by gloo: it exists so that the launcher, rendezvous,
+sharding, gather and JSON assembly of THIS file can be driven by a world-size-2 CPU test; it measures nothing and
+says so in its output.
 """
 from __future__ import annotations
 
@@ -22,8 +35,6 @@ import sys
 import time
 from pathlib import Path
 
-import torch
-
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
@@ -31,7 +42,12 @@ F_UNET = 803.273e9      # algorithmic FLOP per sample-forward
 F_VAE = 2514.519e9      # algorithmic FLOP per decoded image
 PEAK_BF16 = 2.5e15      # dense bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_F32 = 157.3e12
-K_NAMES = ["conv_gemm", "attention", "groupnorm", "layernorm", "other"]
+# af_prof classes (include/adaface_hip.h)
+K_NAMES = ["conv_gemm_other", "attention", "groupnorm", "layernorm", "other", "conv_gemm_pp<160,gather>",
+           "conv_gemm_pp<160,plain>", "conv_gemm_pp<128>"]
+GEMM_CLASSES = (0, 5, 6, 7)
+DOMINANT = 5            # conv_gemm_pp_kernel<160, true>: the 3x3 convolutions, the largest single kernel of a step
+DOMINANT_KERNEL = "conv_gemm_pp_kernel<160, true>"
 
 
 def parse():
@@ -39,17 +55,23 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--workload", default="config1", choices=["config1", "config2", "config3"])
+    ap.add_argument("--batch", type=int, default=8, help="images per UNet micro-batch (CFG forward batch = 2x)")
+    ap.add_argument("--global-batch", type=int, default=None, help="images per step over all ranks (config3: 64)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event roofline leg")
+    ap.add_argument("--no-parity-leg", action="store_true",
+                    help="skip the untimed f32-mode batch (f32-mode images/s and the bf16 final-latent deviation)")
     ap.add_argument("--event-stride", type=int, default=7,
                     help="HIP-event bracket every n-th GEMM / attention launch inside the timed region (1 = all)")
+    ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
 def build_model(device, dtype):
+    import torch
     from adaface_amd.configs import sd15_config
     from ldm.util import instantiate_from_config
     model = instantiate_from_config(sd15_config()["model"]).eval()
@@ -73,6 +95,7 @@ def build_model(device, dtype):
 def cpu_baseline(ddim_steps):
     """Oracle (CPU restatement of the reference, oracle/ldm_oracle.py) on the host cores: one UNet forward at
     CFG batch 2 (= 1/ddim_steps of one image's denoising) + one VAE decode, extrapolated to images/sec."""
+    import torch
     from oracle import ldm_oracle as O
     # one GPU's share of the host is 16 cores; more threads than that oversubscribes the box
     cores = min(os.cpu_count() or 1, 16)
@@ -99,60 +122,113 @@ def cpu_baseline(ddim_steps):
                       f"extrapolated as 1/({ddim_steps}*t_unet + t_vae)"}
 
 
+def traffic_record():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (scripts/pmc_bench.sh: separate
+    FETCH_SIZE / WRITE_SIZE runs, gfx950 corrections) — NOT measured in this run, and labelled so."""
+    tf = ROOT / "profiles" / "traffic_latest.json"
+    if not tf.exists():
+        return None, None
+    try:
+        d = json.loads(tf.read_text())
+    except Exception:
+        return None, None
+    k = (d.get("kernels") or {}).get(DOMINANT_KERNEL)
+    src = {"file": "profiles/traffic_latest.json", "commit": d.get("commit"), "measured_in_run": False,
+           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes of `bench.py --steps 1`, FETCH_SIZE x 2 (gfx950)"}
+    return (k or {}).get("hbm_bytes_per_launch"), src
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: adaface_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # ---- N > 1 without a launcher: start the ranks ourselves, BEFORE anything here touches the GPU ----
+    from adaface_amd.parallel import init_distributed, launch_ranks, launched_by_torchrun
+    if args.gpus > 1 and not launched_by_torchrun():
+        raise SystemExit(launch_ranks(args.gpus, os.fspath(Path(__file__).resolve()), sys.argv[1:]))
+
+    import torch
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
-    from adaface_amd import _lib
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    stub = args.plumbing_test
+    if stub:
+        device = torch.device("cpu")
+        rank, world = init_distributed(args.gpus, backend="gloo")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: adaface_amd has no CPU path")
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        rank, world = init_distributed(args.gpus, backend="nccl", device=device)
     from adaface_amd.parallel import gather_frames, shard_batch
-    from adaface_amd.synth import synth_context
-    from ldm.models.diffusion.ddim import DDIMSampler
-    lib = _lib.load()
+    from adaface_amd.synth import synth_context, synth_context_adaprompt
 
     B, S = args.batch, args.ddim_steps
-    model = build_model(device, args.dtype)
-    sampler = DDIMSampler(model)
+    strong = args.workload == "config3" or args.global_batch is not None
+    G = args.global_batch if args.global_batch is not None else (64 if args.workload == "config3" else B * world)
+    if G % world or (G // world) % B:
+        raise SystemExit(f"global batch {G} must split into micro-batches of {B} on each of {world} rank(s)")
+    n_micro = G // world // B
     # global inputs generated from one seed on the host, sliced per rank (results independent of world size)
     g = torch.Generator().manual_seed(42)
-    x_T = shard_batch(torch.randn(world * B, 4, 64, 64, generator=g), rank, world).to(device)
-    c_emb = shard_batch(synth_context(world * B, seed=100, device="cpu"), rank, world, per_sample=16).to(device)
+    x_T_all = shard_batch(torch.randn(G, 4, 64, 64, generator=g), rank, world).to(device)
+    make_ctx = synth_context_adaprompt if args.workload == "config2" else synth_context
+    c_all = shard_batch(make_ctx(G, seed=100, device="cpu"), rank, world, per_sample=16).to(device)
     uc_emb = synth_context(B, seed=101, device=device, shared=True)
-    c = model.get_learned_conditioning(c_emb)
-    uc = model.get_learned_conditioning(uc_emb)
+
+    if stub:
+        lib = None
+
+        def run_micro(x_T, c_emb):   # deterministic stand-in of the right output shape; NOTHING is measured
+            v = (x_T.sum(dim=(1, 2, 3)) + c_emb.reshape(x_T.shape[0], -1).sum(dim=1)).mul(7).to(torch.uint8)
+            return v[:, None, None, None].expand(-1, 8, 8, 3).contiguous(), x_T
+    else:
+        from adaface_amd import _lib
+        from ldm.models.diffusion.ddim import DDIMSampler
+        lib = _lib.load()
+        model = build_model(device, args.dtype)
+        sampler = DDIMSampler(model)
+        uc = model.get_learned_conditioning(uc_emb)
+        conds = [model.get_learned_conditioning(c_all[i * B * 16:(i + 1) * B * 16]) for i in range(n_micro)]
+
+        def run_micro(x_T, cond):
+            samples, _ = sampler.sample(S=S, conditioning=cond, batch_size=B, shape=[4, 64, 64], verbose=False,
+                                        guidance_scale=[10.0, 4.0], unconditional_conditioning=uc, eta=0.0, x_T=x_T)
+            return model.decode_first_stage_uint8(samples), samples
+
+    last_latent = [None]
+
     def step():
-        samples, _ = sampler.sample(S=S, conditioning=c, batch_size=B, shape=[4, 64, 64], verbose=False,
-                                    guidance_scale=[10.0, 4.0], unconditional_conditioning=uc, eta=0.0, x_T=x_T)
-        frames = model.decode_first_stage_uint8(samples)
-        return gather_frames(frames, global_batch=world * B)  # one RCCL all-gather per batch (no-op at N=1)
+        frames = []
+        for i in range(n_micro):
+            f, lat = run_micro(x_T_all[i * B:(i + 1) * B], c_all[i * B * 16:(i + 1) * B * 16] if stub else conds[i])
+            frames.append(f)
+            last_latent[0] = lat
+        frames = frames[0] if n_micro == 1 else torch.cat(frames)
+        return gather_frames(frames, global_batch=G)  # one RCCL all-gather per step (no-op at N=1)
 
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     fence()
-    timing = not args.no_kernel_timing
+    timing = not args.no_kernel_timing and not stub
     if timing:
         lib.af_prof_reset()
         lib.af_prof_set_stride(args.event_stride)  # sample: an event pair per launch would cost ~10 % of the step
-        lib.af_prof_enable(0b00011)  # conv_gemm + attention
+        lib.af_prof_enable(sum(1 << c for c in GEMM_CLASSES) | 0b10)  # conv/linear kernels + attention
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     fence()
     dt = time.perf_counter() - t0
-    lib.af_prof_enable(0)
-    assert out.shape[-1] == 3 and out.dtype == torch.uint8
+    if lib is not None:
+        lib.af_prof_enable(0)
+    assert out.shape[0] == G and out.shape[-1] == 3 and out.dtype == torch.uint8
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -167,48 +243,77 @@ def main():
         flops = (C.c_double * n)()
         byts = (C.c_double * n)()
         _lib.check(lib.af_prof_collect(n, ms, launches, flops, byts), "af_prof_collect")
+        peak = PEAK_BF16 if args.dtype == "bf16" else PEAK_F32
         for i, k in enumerate(K_NAMES):
             if launches[i]:
-                kernels[k] = {"launches": int(launches[i]), "ms_total": ms[i], "avg_us": 1e3 * ms[i] / launches[i],
-                              "algorithmic_tflops": flops[i] / (ms[i] * 1e-3) / 1e12 if flops[i] else None}
-        if launches[0]:
-            peak = PEAK_BF16 if args.dtype == "bf16" else PEAK_F32
-            ach = flops[0] / (ms[0] * 1e-3)
-            traffic = None
-            tf = ROOT / "profiles" / "traffic_latest.json"
-            if tf.exists():
-                try:
-                    traffic = json.loads(tf.read_text()).get("conv_gemm_hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roof = {"kernel": "conv/linear class: conv_gemm_pp_kernel (256x160 ping-pong) + conv_gemm_kernel + splitk_reduce, all shapes",
-                    "bound": "mfma", "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                    "frac": ach / peak, "traffic": traffic,
-                    "flops_per_launch": flops[0] / launches[0], "avg_launch_us": 1e3 * ms[0] / launches[0],
-                    "launches": int(launches[0]), "sampled_every": args.event_stride}
+                kernels[k] = {"launches_timed": int(launches[i]), "ms_total": ms[i], "avg_us": 1e3 * ms[i] / launches[i],
+                              "algorithmic_tflops": flops[i] / (ms[i] * 1e-3) / 1e12 if flops[i] else None,
+                              "algorithmic_bytes_per_launch": byts[i] / launches[i]}
+        cls_ms = sum(ms[c] for c in GEMM_CLASSES)
+        cls_fl = sum(flops[c] for c in GEMM_CLASSES)
+        cls_n = sum(launches[c] for c in GEMM_CLASSES)
+        # the f32 parity mode has no ping-pong kernel: its dominant kernel is the four-wave / halo class
+        d = DOMINANT if launches[DOMINANT] else 0
+        if launches[d]:
+            traffic, tsrc = traffic_record() if d == DOMINANT else (None, None)
+            ach = flops[d] / (ms[d] * 1e-3)
+            roof = {"kernel": DOMINANT_KERNEL + " (3x3 / strided convolutions of the UNet and VAE: eight-wave 256x160x64 "
+                              "ping-pong implicit GEMM, LDS-DMA ring)" if d == DOMINANT else "conv_gemm_kernel / conv3x3_halo_kernel (f32 parity mode)",
+                    "bound": "mfma", "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
+                    "flops_per_launch": flops[d] / launches[d], "avg_launch_us": 1e3 * ms[d] / launches[d],
+                    "launches_timed": int(launches[d]), "sampled_every": args.event_stride,
+                    "algorithmic_bytes_per_launch": byts[d] / launches[d],
+                    "traffic": traffic, "traffic_source": tsrc,
+                    "conv_linear_class": {"kernels": [K_NAMES[c] for c in GEMM_CLASSES], "achieved": cls_fl / (cls_ms * 1e-3) / 1e12,
+                                          "frac": cls_fl / (cls_ms * 1e-3) / peak, "launches_timed": int(cls_n)}}
+
+    # ---- untimed parity leg (rank 0, N = 1): the SAME batch in f32 parity mode ----
+    parity = None
+    if rank == 0 and world == 1 and not stub and not args.no_parity_leg and args.dtype == "bf16":
+        lat16 = last_latent[0].clone()
+        model.set_compute_dtype("f32")
+        run_micro(x_T_all[(n_micro - 1) * B:], conds[-1])          # engine build + weight upload + first call
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        _, lat32 = run_micro(x_T_all[(n_micro - 1) * B:], conds[-1])
+        torch.cuda.synchronize()
+        t32 = time.perf_counter() - t1
+        sc = lat32.abs().max().item()
+        parity = {"f32_mode_images_per_sec": B / t32,
+                  "bf16_final_latent_rel_err": (lat16 - lat32).abs().max().item() / sc,
+                  "bf16_final_latent_max_abs_err": (lat16 - lat32).abs().max().item(), "final_latent_max_abs": sc,
+                  "note": "same x_T / context / weights; the f32 (parity) mode is the one pinned to <= 1e-3 max-abs "
+                          "against the CPU oracle (tests/test_model_gpu.py::test_config0_*, profiles/*parity_50step*); "
+                          "bf16 is the timed throughput mode and this is its measured deviation after all DDIM steps"}
+        model.set_compute_dtype(args.dtype)
 
     if rank == 0:
-        images = world * B * args.steps
+        images = G * args.steps
         value = images / dt
+        flop_img = S * 2 * F_UNET + F_VAE
         res = {
             "metric": "512x512 images/sec @ 50 DDIM steps, batch 8",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"SD v1.5 512x512, {S} DDIM steps, batch {B} per GPU, CFG (Bf={2 * B}), "
-                                   "layerwise 16x77x768 context, random-init weights", "global_batch": world * B,
-                       "latent": [4, 64, 64], "guidance_scale": [10.0, 4.0], "parallelism": f"dp{world}"},
-            "whole_path_algorithmic_tflops": value * (S * 2 * F_UNET + F_VAE) / 1e12 / world,
-            "whole_path_frac_of_mfma_peak": value * (S * 2 * F_UNET + F_VAE) / world /
-                                            (PEAK_BF16 if args.dtype == "bf16" else PEAK_F32),
-            "roofline": roof, "kernels": kernels,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: SD v1.5 512x512, {S} DDIM steps, batch {B} per forward "
+                                   f"(CFG Bf={2 * B}), {n_micro} micro-batch(es) per GPU per step, layerwise 16x77x768 context"
+                                   + (" with per-layer AdaPrompt subject rows 6..21" if args.workload == "config2" else "")
+                                   + ", random-init weights",
+                       "global_batch": G, "latent": [4, 64, 64], "guidance_scale": [10.0, 4.0], "parallelism": f"dp{world}"},
+            "whole_path_algorithmic_tflops": value * flop_img / 1e12 / world,
+            "whole_path_frac_of_mfma_peak": value * flop_img / world / (PEAK_BF16 if args.dtype == "bf16" else PEAK_F32),
+            "roofline": roof, "kernels": kernels, "parity": parity,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if stub:
+            res.update(metric="PLUMBING TEST - stub in place of the HIP path, nothing measured", value=None, dtype="none",
+                       checksum=int(out.to(torch.int64).sum().item()))
+        if world == 1 and not args.no_cpu_baseline and not stub:
             res["cpu_baseline"] = cpu_baseline(S)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -90,6 +90,16 @@ int af_set_context(af_handle* h, const float* ctx_dev, int Bf, int n_tokens, int
 int af_unet_forward(af_handle* h, const float* x_dev, const int64_t* t_dev, float* eps_dev, int Bf, int H, int W,
                     void* stream);
 
+/* Diagnostic tap on the U-Net's block outputs (what a forward hook on input_blocks[i] / middle_block / output_blocks[j]
+ * of the reference UNetModel sees, openaimodel.py:984-1027): blocks are numbered in forward order, input_blocks
+ * 0..n_in-1, middle_block = n_in, output_blocks = n_in+1+j.  af_unet_block_shape gives the (C, H, W) of a block's
+ * output for an H x W latent; af_unet_set_tap makes every following af_unet_forward also write that block's output as
+ * fp32 NCHW [Bf, C, H, W] to out_dev (block < 0 or out_dev NULL: off).  Used by the parity tests to localise a
+ * deviation; costs nothing when off. */
+int af_unet_num_blocks(af_handle* h);
+int af_unet_block_shape(af_handle* h, int block, int H, int W, int* C_out, int* H_out, int* W_out);
+int af_unet_set_tap(af_handle* h, int block, float* out_dev);
+
 /* p_sample_ddim's CFG combine + x_{t-1} update (ddim.py:260,273-295), fp32, n elements.
  * eps_uncond_dev / noise_dev / pred_x0_dev may be NULL. */
 int af_ddim_step(const float* x_dev, const float* eps_cond_dev, const float* eps_uncond_dev, const float* noise_dev,
@@ -123,7 +133,9 @@ int af_to_uint8(const float* img_dev, uint8_t* u8_dev, int B, int H, int W, void
 int64_t af_arena_bytes(af_handle* h);
 
 /* ---- per-kernel-class HIP-event timing (bench.py roofline leg) ----
- * classes: 0 conv_gemm (implicit-GEMM conv/linear), 1 attention, 2 groupnorm, 3 layernorm, 4 other.
+ * classes: 0 conv_gemm (implicit-GEMM conv/linear on the four-wave / halo kernels), 1 attention, 2 groupnorm,
+ * 3 layernorm, 4 other, 5 conv_gemm_pp_kernel<160,gather> (3x3 / strided convs on the eight-wave ping-pong kernel),
+ * 6 conv_gemm_pp_kernel<160,plain> (1x1 convs / linears), 7 conv_gemm_pp_kernel<128,*> (GEGLU, VAE widths).
  * While enabled every launch of a class is bracketed by hipEventRecord on ITS stream; af_prof_collect
  * sums elapsed ms, launch counts and the ALGORITHMIC flops / bytes of those launches per class. */
 int af_prof_enable(int class_mask); /* bit c set = time class c; 0 = off */
@@ -136,6 +148,21 @@ int af_prof_collect(int n_classes, double* ms, int64_t* launches, double* flops,
  * tile: 0-3 = 128x128 / 64x128 / 128x64 / 64x64 four-wave tiles, 4 / 5 = 256x128 / 256x160 eight-wave ping-pong tiles;
  * halo_tw != 0: LDS-halo 3x3 kernel.  The parity tests use it to assert which kernel they exercised. */
 int af_last_gemm_plan(int* tile, int* splitk, int* halo_tw);
+/* launches per tiling since the last reset: counts8[0..5] by tile (as af_last_gemm_plan), [6] LDS-halo 3x3 kernel,
+ * [7] launches that sliced K (also counted under their tile).  Lets a whole-model test assert which kernels it ran. */
+int af_gemm_plan_counts(int64_t* counts8);
+int af_gemm_plan_counts_reset(void);
+
+/* ---- tuning / diagnostic knobs ----
+ * The planner thresholds and "force this kernel variant" switches live in one struct that is filled once from the
+ * AF_* environment variables when the library is loaded (AF_GEMM_PP_MINFILL -> "gemm_pp_minfill", ...); nothing on the
+ * launch path reads the environment.  The parity tests use af_knob_set to reach a kernel variant regardless of the
+ * planner's choice and af_knob_reset to restore the load-time values.  No knob changes results beyond the summation
+ * order of the chosen tiling.  Names: splitk_target, conv_halo, gemm_pp, gemm_pp_geglu_minkt, gemm_pp_minfill,
+ * gemm_tile, gemm_splitk, gemm_groupm, gemm_dma, pp_direct, attn_w4, gn_small, gn_fold. */
+int af_knob_set(const char* name, int value);
+int af_knob_get(const char* name, int* value);
+int af_knob_reset(void);
 
 /* ---- operator-level entry points (parity tests; reference layouts, fp32 device tensors) ----
  * Each converts to the internal NHWC `dtype` layout, runs the same kernel the model

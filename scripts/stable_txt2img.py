@@ -8,7 +8,8 @@ EmbeddingManager are out of scope offline, so prompts are giv
 (--prompt_emb file.pt/.npy with a [B*16,77,768] or [77,768] tensor) or --synthetic.
 
     python scripts/stable_txt2img.py --synthetic --n_samples 8 --ddim_steps 50 --skip_save
-    torchrun --nproc-per-node 8 --master-addr 127.0.0.1 scripts/stable_txt2img.py --synthetic --n_samples 64
+    python scripts/stable_txt2img.py --synthetic --n_samples 64 --gpus 8      # starts the 8 ranks itself
+    torchrun --nproc-per-node 8 --master-addr 127.0.0.1 scripts/stable_txt2img.py --synthetic --n_samples 64 --gpus 8
 """
 from __future__ import annotations
 
@@ -50,6 +51,8 @@ def parse_args():
     ap.add_argument("--plms", action="store_true", help="PLMS sampler instead of DDIM (scalar --scale)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--gpu", type=int, default=None)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="data-parallel ranks (one process per GPU); without a launcher the ranks are started here")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     return ap.parse_args()
 
@@ -76,15 +79,15 @@ def load_emb(path, n, device):
 def main():
     opt = parse_args()
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    from adaface_amd.parallel import init_distributed, launch_ranks, launched_by_torchrun
+    if opt.gpus > 1 and not launched_by_torchrun():   # before this process touches the GPU
+        raise SystemExit(launch_ranks(opt.gpus, os.fspath(Path(__file__).resolve()), sys.argv[1:]))
     local = int(os.environ.get("LOCAL_RANK", "0")) if opt.gpu is None else opt.gpu
     if not torch.cuda.is_available():
         raise SystemExit("no HIP device: adaface_amd has no CPU path (use the reference for CPU plumbing runs)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    rank, world = init_distributed(opt.gpus, backend="nccl", device=device)   # fails if the group is not opt.gpus ranks
     from adaface_amd.configs import sd15_config
     from adaface_amd.parallel import gather_frames, shard_batch, shard_range
     from adaface_amd.synth import synth_context
@@ -169,7 +172,7 @@ def main():
         n_img = B * opt.n_repeat
         print(f"{n_img} images of {opt.H}x{opt.W} @ {opt.ddim_steps} DDIM steps in {toc - tic:.2f} s "
               f"({n_img / (toc - tic):.2f} images/s incl. first-call warm-up) on {world} GPU(s); outputs: {opt.outdir}")
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -38,3 +38,11 @@ def gpu():
     from adaface_amd import _lib
     _lib.load()  # fail loudly if the HIP library is missing
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def knobs(gpu):
+    """Set planner / kernel-variant knobs through the C ABI (af_knob_set) for one test; load-time values restored after."""
+    from adaface_amd import _lib
+    yield _lib.set_knob
+    _lib.reset_knobs()

@@ -171,3 +171,50 @@ def test_gloo_world2_shard_and_gather(ragged):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert all(shape[0] == (5 if ragged else 4) for _, _, shape in res)
+
+
+# ------------------------------------------------------------------ bench.py's own launcher path (gloo, CPU) ----
+def _run_bench(args, env=None, timeout=300):
+    import json
+    import subprocess
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None), e.pop("RANK", None), e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, env=e, timeout=timeout)
+    line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{")), None)
+    return r, (json.loads(line) if line else None)
+
+
+def test_bench_launches_its_own_ranks_gloo_world2():
+    """`python bench.py --gpus 2` with no launcher in the environment must start two ranks itself (fresh processes under
+    torch.distributed.run), report the number of ranks the group connected, and produce the same gathered frames as one
+    rank — driven here with the HIP path stubbed out (--plumbing-test, gloo): launcher, rendezvous on 127.0.0.1,
+    shard_batch, micro-batching, gather_frames, max-over-ranks timing and the JSON line are bench.py's real code."""
+    common = ["--plumbing-test", "--steps", "2", "--warmup", "1", "--batch", "2", "--global-batch", "8"]
+    r2, j2 = _run_bench(["--gpus", "2", *common])
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    r1, j1 = _run_bench(["--gpus", "1", *common])
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    assert j2["n_gpus"] == 2 and j1["n_gpus"] == 1
+    assert j2["config"]["global_batch"] == 8 and j2["scaling"] == "strong" and j2["value"] is None
+    assert j2["checksum"] == j1["checksum"]            # results do not depend on the world size
+    assert "PLUMBING TEST" in j2["metric"]
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """--gpus 4 inside a 2-rank launch must fail instead of silently measuring fewer GPUs."""
+    r, j = _run_bench(["--gpus", "4", "--plumbing-test", "--steps", "1", "--warmup", "0"],
+                      env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                           "MASTER_PORT": str(_free_port())}, timeout=120)
+    assert r.returncode != 0 and j is None
+    assert "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_adaprompt_context_differs_per_layer_only_in_subject_rows():
+    from adaface_amd.synth import synth_context, synth_context_adaprompt
+    c = synth_context_adaprompt(3, seed=100, device="cpu").reshape(3, 16, 77, 768)
+    base = synth_context(3, seed=100, device="cpu").reshape(3, 16, 77, 768)
+    assert torch.equal(c[:, :, :6], base[:, :, :6]) and torch.equal(c[:, :, 22:], base[:, :, 22:])
+    assert (c[:, 0, :6] == c[:, 5, :6]).all()                      # plain rows identical over the 16 layer copies
+    assert not torch.equal(c[:, 0, 6:22], c[:, 1, 6:22])           # subject rows drawn per layer
+    assert abs(c[:, :, 6:22].std().item() - 0.07) < 0.005

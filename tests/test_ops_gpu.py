@@ -150,12 +150,12 @@ def _last_plan():
     (2, 64, 16, 16, 160, 1, 1, False, True, False, 1),    # KT = 1: prologue-only pipeline
     (2, 128, 16, 16, 160, 1, 1, False, True, False, 1),   # KT = 2
 ])
-def test_conv2d_pingpong(gpu, report, monkeypatch, B, Cin, H, W, Cout, ks, stride, up, bias, res, splitk):
+def test_conv2d_pingpong(gpu, report, knobs, B, Cin, H, W, Cout, ks, stride, up, bias, res, splitk):
     """The eight-wave 256x{160,128} ping-pong kernel (conv_gemm_pp_kernel), forced regardless of grid fill."""
     from adaface_amd import ops
-    monkeypatch.setenv("AF_GEMM_PP_MINFILL", "0")
+    knobs("gemm_pp_minfill", 0)
     if splitk > 1:
-        monkeypatch.setenv("AF_GEMM_SPLITK", str(splitk))
+        knobs("gemm_splitk", splitk)
     dtype = "bf16"
     g = torch.Generator().manual_seed(Cin + Cout + H + ks + 1)
     x = _q(torch.randn(B, Cin, H, W, generator=g), dtype)
@@ -178,11 +178,11 @@ def test_conv2d_pingpong(gpu, report, monkeypatch, B, Cin, H, W, Cout, ks, strid
     (512, 64, 160, True, False, False), (4096, 320, 1280, True, False, True), (700, 640, 2560, True, False, True),
     (1024, 1280, 5120, False, False, True),
 ])
-def test_linear_pingpong(gpu, report, monkeypatch, M, K, N, bias, res, geglu):
+def test_linear_pingpong(gpu, report, knobs, M, K, N, bias, res, geglu):
     """Linear / GEGLU through the ping-pong kernel (GEGLU: 256x128 tile, value|gate interleaved in 16-row groups)."""
     from adaface_amd import ops
-    monkeypatch.setenv("AF_GEMM_PP_MINFILL", "0")
-    monkeypatch.setenv("AF_GEMM_PP_GEGLU_MINKT", "0")
+    knobs("gemm_pp_minfill", 0)
+    knobs("gemm_pp_geglu_minkt", 0)
     dtype = "bf16"
     g = torch.Generator().manual_seed(M + K + N + 1)
     x = _q(torch.randn(M, K, generator=g), dtype)
@@ -285,14 +285,47 @@ def test_lincomb(gpu, report):
 
 
 def test_to_uint8(gpu):
+    """Byte output is asserted EXACTLY: the kernel restates the reference's fp32 op order, clamp((x + 1) / 2, 0, 1)
+    (stable_txt2img.py:715) then 255. * x truncated by astype(uint8) (:764-765); values landing exactly on a byte
+    boundary and far outside [-1, 1] are in the input on purpose."""
     from adaface_amd import ops
     g = torch.Generator().manual_seed(3)
     img = torch.randn(2, 3, 32, 48, generator=g)
-    ref = (torch.clamp((img + 1) / 2, 0, 1).permute(0, 2, 3, 1).numpy() * 255).astype("uint8")
+    edge = torch.tensor([-1.0, 1.0, -3.0, 3.0, 0.0, -0.0, 2.0 / 255 * 127 - 1.0, 1.0 - 2.0 ** -23, -1.0 + 2.0 ** -23,
+                         254.0 / 255 * 2 - 1, 0.5, -0.5])
+    img.view(-1)[: edge.numel()] = edge
+    k = torch.arange(256, dtype=torch.float32)            # x with 255 * clamp((x + 1) / 2) at / next to integer k
+    img.view(-1)[100:356] = k / 255.0 * 2.0 - 1.0
+    img.view(-1)[400:656] = torch.nextafter(k / 255.0 * 2.0 - 1.0, torch.tensor(-4.0))
+    ref = (255.0 * torch.clamp((img + 1.0) / 2.0, min=0.0, max=1.0).permute(0, 2, 3, 1).numpy()).astype("uint8")
     got = ops.to_uint8(img.to(gpu)).cpu().numpy()
-    # identical arithmetic up to fp32 rounding of x*255: allow off-by-one on exact boundaries
-    assert (abs(got.astype(int) - ref.astype(int)) <= 1).all()
-    assert (got != ref).mean() < 1e-3
+    assert got.dtype == ref.dtype and got.shape == ref.shape
+    assert (got == ref).all(), int((got != ref).sum())
+
+
+def test_attention_spiky_bf16_dh40(gpu, report):
+    """bf16 dh = 40 kernel (the 64x64 self-attention instantiation): its softmax reference rides in a spare K slot of
+    the QK^T MFMA and moves after the first tile only when a score rises more than 2^24 (log2 domain) above it.  A key
+    in a LATE tile that scores far above everything before it forces that rare fix-up branch (rescale of O, refresh of
+    the Q-side slot) in some query blocks; queries that do not see the spike take the common path in the same launch."""
+    from adaface_amd import ops
+    g = torch.Generator().manual_seed(6)
+    B, N, heads, dh = 1, 512, 8, 40
+    q = _q(torch.randn(B, N, heads * dh, generator=g), "bf16")
+    k = _q(torch.randn(B, N, heads * dh, generator=g), "bf16")
+    v = _q(torch.randn(B, N, heads * dh, generator=g), "bf16")
+    # head 0..7 of query 17 / 300: key 330 (6th tile) aligned with the query and 6x longer: score ~ +6 |q|^2 / sqrt(40)
+    # ~ 38 natural units = 55 in the log2 domain, against tile-0 maxima of a few units
+    k[:, 330] = _q(q[:, 17] * 6.0, "bf16")
+    k[:, 470] = _q(q[:, 300] * 6.0, "bf16")
+    ref = _ref_attention(q, k, v, heads)
+    sim = torch.einsum("bid,bjd->bij", q[..., :dh], k[..., :dh]) * dh ** -0.5 * math.log2(math.e)
+    assert (sim[0, 17, 330] - sim[0, 17, :64].max()).item() > 24.0    # the branch condition really is met
+    got = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), heads, dtype="bf16")
+    _cmp(report, "attention spiky dh40 (m_ref move at a late tile)", got, ref, "bf16")
+    # and the two spiked queries on their own: their output is essentially v[330] / v[470]
+    assert (got[0, 17].cpu() - ref[0, 17]).abs().max() <= 3e-2 * ref.abs().max()
+    assert (got[0, 300].cpu() - ref[0, 300]).abs().max() <= 3e-2 * ref.abs().max()
 
 
 # ---------------------------------------------------------------------------------------------------------------
