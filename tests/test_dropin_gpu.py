@@ -42,7 +42,7 @@ def test_apply_model_matches_reference_golden(gpu, report, tiny_model):
     assert "ca_layers_activations" in cond[2]
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 2e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-4), ("bf16", 3e-2)])
 def test_apply_model_conv_attention_matches_reference(gpu, report, tiny_model, mode, tol):
     """Subject-token 3x3 conv attention (extra_info use_conv_attn_kernel_size / placeholder2indices; attention.py:208-216,
     util.py:701-879) through the drop-in UNet vs the reference UNet's output with the same extra_info."""

@@ -2,7 +2,7 @@
 
 Each HIP kernel is reached through the C ABI (af_op_*).  Two storage/MFMA modes:
   f32  : parity mode (f32 MFMA, exact fp32 products) — tolerance 2e-4 of the output scale
-  bf16 : throughput mode (bf16 MFMA, fp32 accumulate)  — tolerance 3e-2 of the output scale
+  bf16 : throughput mode (bf16 MFMA, fp32 accumulate)  — tolerance 1.5e-2 of the output scale (observed <= 7.7e-3)
 Tolerances are relative to max|reference| and are stated here, not tuned per case.
 """
 import math
@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"f32": 2e-4, "bf16": 3e-2}
+TOL = {"f32": 2e-4, "bf16": 1.5e-2}   # bf16: largest observed over all cases 7.7e-3 (gpurun_out/parity_report.txt)
 
 
 def _cmp(report, name, got, ref, dtype, tol_scale=1.0):
@@ -324,8 +324,8 @@ def test_attention_spiky_bf16_dh40(gpu, report):
     got = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), heads, dtype="bf16")
     _cmp(report, "attention spiky dh40 (m_ref move at a late tile)", got, ref, "bf16")
     # and the two spiked queries on their own: their output is essentially v[330] / v[470]
-    assert (got[0, 17].cpu() - ref[0, 17]).abs().max() <= 3e-2 * ref.abs().max()
-    assert (got[0, 300].cpu() - ref[0, 300]).abs().max() <= 3e-2 * ref.abs().max()
+    assert (got[0, 17].cpu() - ref[0, 17]).abs().max() <= 1.5e-2 * ref.abs().max()
+    assert (got[0, 300].cpu() - ref[0, 300]).abs().max() <= 1.5e-2 * ref.abs().max()
 
 
 # ---------------------------------------------------------------------------------------------------------------
