@@ -60,10 +60,17 @@ template <typename T, int DH> struct AttnCfg {
   static constexpr int MREF_STEP = (DH * 2) / 32, MREF_HALF = ((DH * 2) % 32) / 16, MREF_ELEM = (((DH * 2) % 32) % 16) / 2;
 };
 
+// max over the two lane halves (lane l <-> lane l ^ 32).  v_permlane32_swap exchanges the upper half of its first operand
+// with the lower half of its second: afterwards a = (low | low) and b = (high | high) of the input.  The swap is inline
+// asm on purpose: through __builtin_amdgcn_permlane32_swap hipcc (ROCm 7.2) treats the two results as one value and folds
+// fmaxf(r[0], r[1]) to r[0] — every lane then got the LOWER half's maximum only, which went unnoticed on ordinary data
+// (any reference below the true maximum is still a valid softmax shift) and produced inf / NaN once a key held by the upper
+// half scored 2^128 above the rest (tests/test_ops_gpu.py::test_attention_spiky_bf16_dh40).  The s_nop 1 covers the
+// "VALU write -> v_permlane read" hazard for whatever wrote the operands.
 __device__ __forceinline__ float xhalf_max(float v) {
-  const unsigned b = __builtin_bit_cast(unsigned, v);
-  const u32x2 r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
 }
 
 // smallest bf16-representable value >= x, as fp32
@@ -364,6 +371,283 @@ template <typename T, int DH> __device__ __forceinline__ void attn_body(const At
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// dh = 40, bf16: the 64x64-level attention (self N = S = 4096: 14 % of a denoising step; cross S = 77).
+//
+// What the lab (scripts/lab/attn_lab.hip, interleaved A/B runs on one device) showed about the four-wave kernel above at
+// this shape: with QK^T, softmax and PV removed it still took 55 % of its time — staging K/V through registers with a
+// one-tile prefetch exposes the L2 latency (about 1 us under load) once per tile, and the 80-byte head slices of the
+// [B][N][3C] activation cost 2.5x their size in cache-line traffic.  This kernel therefore
+//   * shares every staged K/V tile among EIGHT waves (256 queries per workgroup, two workgroups per CU): half the
+//     staging traffic and LDS writes per query;
+//   * stages by LDS-DMA (buffer_load ... lds): no VGPR round trip, no ds_write, no "vmcnt(0) then store" in the middle
+//     of each wave's instruction stream; tile t+1 is in flight while tile t is multiplied.  LDS-DMA writes lane-
+//     linearly (wave-uniform base + 16 * lane), so padding and swizzle live in the per-lane SOURCE address and in the
+//     EXEC mask (pad lanes are masked off):
+//       K image: 64 rows x 112 B = 5 data chunks | [1.0, 0 x7] (the K side of the "-m_ref" slot, set once) | zeros
+//       V image: 64 rows x 128 B = 5 data chunks | [1.0, 0 x7] (the ones column that sums the denominator) | 2 x zeros,
+//                the two 64-byte halves of rows with bit 1 set swapped, so that the four rows a ds_read_b64_tr_b16
+//                half touches cover all 64 banks (a plain 128-B stride would be 2-way);
+//     rows >= Nk lie beyond the buffer resource's num_records and are zero-filled by the hardware range check;
+//   * reads its fragments by inline asm with hand-counted lgkmcnt: hipcc puts s_waitcnt vmcnt(0) in front of every LDS
+//     read it can see while an LDS-DMA is outstanding, which would expose the whole load latency each tile;
+//   * takes the softmax reference m_ref from the FIRST tile only (it rides in the spare K slot of the QK^T MFMA, as
+//     above) and runs no per-tile maximum afterwards: 18 v_max3 + the fix-up test per tile gone.  exp2(s - m_ref) can
+//     then exceed 1, which is harmless (fp32 / bf16 exponents have the range; O / l is scale free) unless it overflows:
+//     a score more than 2^127 above the first tile's maximum makes P, l or O non-finite — that, and only that, is
+//     detected at the end (per lane, then per workgroup) and the workgroup repeats its block with the running-reference
+//     loop of the kernel above.  tests/test_ops_gpu.py::test_attention_spiky_bf16_dh40 forces both paths.
+// Measured (MI355X, lab, same random data, one process): 487-517 us -> 391-412 us for N = S = 4096, B = 16, H = 8.
+// ---------------------------------------------------------------------------------------------------------------
+namespace ring40 {
+constexpr int DH = 40, FS = 3, DB = 2, WAVES = 8, NT = WAVES * 64;
+constexpr int KROW = 112, VROW = 128;
+constexpr int K_BYTES = 64 * KROW, V_BYTES = 64 * VROW, BUF = K_BYTES + V_BYTES;   // 7168 + 8192
+constexpr int KP = K_BYTES / 1024, VP = V_BYTES / 1024, NPIECE = KP + VP;          // 7 + 8 pieces of 1 KiB
+constexpr int PPW = (NPIECE + WAVES - 1) / WAVES;                                  // 2 (wave 7: 1)
+constexpr int NBUF = 2;
+constexpr int LDS_BYTES = NBUF * BUF;
+constexpr int MREF_STEP = 2, MREF_HALF = 1, MREF_ELEM = 0;   // d = 40 -> byte 80: step 2 (64..95), half 1, element 0
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // (HIP's uint4 / uint2 are structs: asm operands must be vectors)
+
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_base, unsigned voffset, unsigned soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_base, 16, voffset, soffset, 0, 0);
+#endif
+}
+template <int OFF> __device__ __forceinline__ u32x4 lds_read128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int OFF> __device__ __forceinline__ u32x2 lds_read_tr64(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+// the wait names the registers it covers ("+v"): no consumer of them can be scheduled above it (cdna guide 5.7, form ii)
+template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkm2(u32x2& a, u32x2& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+__device__ __forceinline__ void mma(const u32x4& a, const uint4& b, f32x16& c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// one pass over the keys for this workgroup's 256 queries.  RUNMAX = false: reference from the first tile only;
+// returns whether this lane saw a non-finite result (outputs are written either way; a repeat overwrites them).
+template <bool RUNMAX> __device__ __forceinline__ bool pass(const AttnParams& p, char* smem) {
+  typedef bf16 T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q = blockIdx.x * (WAVES * 32) + wave * 32 + l31;
+  const bool q_ok = q < p.Nq;
+  const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * p.bsq + head * DH;
+  const T* K = reinterpret_cast<const T*>(p.k) + (long)b * p.bsk + head * DH;
+  const T* V = reinterpret_cast<const T*>(p.v) + (long)b * p.bsv + head * DH;
+  T* O = reinterpret_cast<T*>(p.o) + (long)b * p.bso + head * DH;
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(K), 0, (p.Nk - 1) * p.ldk * 2 + DH * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(V), 0, (p.Nk - 1) * p.ldv * 2 + DH * 2, 0x00020000);
+
+  // Q fragments (B operand of S^T = K Q^T), pre-multiplied by scale*log2(e): the wave's OLDEST vector-memory operations
+  const float sl2 = p.scale * 1.44269504088896340736f;
+  uint4 qf[FS];
+#pragma unroll
+  for (int s = 0; s < FS; ++s) {
+    const int d0 = (32 * s + 16 * h) / 2;
+    Vec16<T> v;
+    v.u = make_uint4(0, 0, 0, 0);
+    if (q_ok && d0 < DH) v.u = *reinterpret_cast<const uint4*>(Q + (long)q * p.ldq + d0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v.e[e] = from_f32<T>(to_f32<T>(v.e[e]) * sl2);
+    qf[s] = v.u;
+  }
+  // ---- DMA pieces of this wave: piece = wave + 8 j; pieces 0..6 = K image, 7..14 = V image.  Lane -> (row, chunk) of
+  // the image; chunk >= 5 = pad (lane masked off) ----
+  unsigned voff[PPW];
+  bool act[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int piece = wave + WAVES * j;
+    if (piece < KP) {
+      const int g = piece * 64 + lane, row = g / 7, c = g - row * 7;
+      act[j] = c < 5;
+      voff[j] = (unsigned)(row * p.ldk * 2 + c * 16);
+    } else {
+      const int g = (piece - KP) * 64 + lane, row = g >> 3, c = (g & 7) ^ (((row >> 1) & 1) << 2);
+      act[j] = c < 5 && piece < NPIECE;
+      voff[j] = (unsigned)(row * p.ldv * 2 + c * 16);
+    }
+  }
+  auto stage = [&](int buf, int t0) {
+    char* base = smem + buf * BUF;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int piece = wave + WAVES * j;
+      if (piece >= NPIECE) continue;
+      if (piece < KP) { if (act[j]) lds_dma16(rs_k, base + piece * 1024, voff[j], (unsigned)(t0 * p.ldk * 2)); }
+      else { if (act[j]) lds_dma16(rs_v, base + K_BYTES + (piece - KP) * 1024, voff[j], (unsigned)(t0 * p.ldv * 2)); }
+    }
+  };
+  const int nt = (p.Nk + 63) / 64;
+  stage(0, 0);
+  // pads of both buffers (disjoint from everything the DMA writes; never written again)
+  for (int idx = tid; idx < NBUF * 320; idx += NT) {
+    const int bufi = idx / 320, r = idx - bufi * 320;
+    char* base = smem + bufi * BUF;
+    if (r < 128) {
+      const int row = r >> 1, c = 5 + (r & 1);
+      *reinterpret_cast<uint4*>(base + row * KROW + c * 16) = make_uint4(c == 5 ? 0x3F80u : 0u, 0, 0, 0);
+    } else {
+      const int rr2 = r - 128, row = rr2 / 3, c = 5 + (rr2 - row * 3);
+      const int pos = c ^ (((row >> 1) & 1) << 2);
+      *reinterpret_cast<uint4*>(base + K_BYTES + row * VROW + pos * 16) = make_uint4(c == 5 ? 0x3F80u : 0u, 0, 0, 0);
+    }
+  }
+  f32x16 o[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = 0.f;
+  // fragment read addresses (per lane): K row l31 at 16 h; V rows 4 h + tq, swizzled 64-byte half, 8 tp + 32 gi
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) char*)smem);
+  const unsigned kaddr0 = lds0 + (unsigned)(l31 * KROW + 16 * h);
+  const int tq = (lane & 15) >> 2, tp = lane & 3, gi = (lane >> 4) & 1;
+  const int vrow0 = 4 * h + tq, sw = (vrow0 >> 1) & 1;
+  const unsigned vaddr0 = lds0 + (unsigned)(K_BYTES + vrow0 * VROW + 32 * gi + 8 * tp);
+  const unsigned vh0 = (unsigned)(64 * (0 ^ sw)), vh1 = (unsigned)(64 * (1 ^ sw));
+
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own pieces of tile 0 landed, own pads written
+  __builtin_amdgcn_s_barrier();
+
+  for (int t = 0; t < nt; ++t) {
+    const int t0 = t * 64;
+    const unsigned bo = (unsigned)((t & 1) * BUF);
+    if (t + 1 < nt) stage((t + 1) & 1, t0 + 64);   // its last readers passed the barrier that ended tile t-1
+    // ---- S^T = K Q^T : two 32-key blocks (scores already in the log2 domain, minus m_ref through the spare slot) ----
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+    {
+      const unsigned ka = kaddr0 + bo;
+      u32x4 a00 = lds_read128<0 * 32 * KROW + 0>(ka), a01 = lds_read128<0 * 32 * KROW + 32>(ka), a02 = lds_read128<0 * 32 * KROW + 64>(ka);
+      u32x4 a10 = lds_read128<1 * 32 * KROW + 0>(ka), a11 = lds_read128<1 * 32 * KROW + 32>(ka), a12 = lds_read128<1 * 32 * KROW + 64>(ka);
+      wait_lgkm<5>(a00); mma(a00, qf[0], s[0]);
+      wait_lgkm<4>(a01); mma(a01, qf[1], s[0]);
+      wait_lgkm<3>(a02); mma(a02, qf[2], s[0]);
+      wait_lgkm<2>(a10); mma(a10, qf[0], s[1]);
+      wait_lgkm<1>(a11); mma(a11, qf[1], s[1]);
+      wait_lgkm<0>(a12); mma(a12, qf[2], s[1]);
+    }
+    if (t0 + 64 > p.Nk) {  // partial last tile: mask keys >= Nk (wave-uniform branch)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t0 + 32 * kb + acc_row(r, h) >= p.Nk) s[kb][r] = -INFINITY;
+    }
+    if (RUNMAX || t == 0) {
+      // tile maximum (see the kernel above for the wait states in front of the asm reads of MFMA results)
+      float mxa, mxb, mxc, mxd;
+      asm("s_nop 15\n\t"
+          "v_max3_f32 %0, %4, %5, %6\n\t"
+          "v_max3_f32 %1, %7, %8, %9\n\t"
+          "v_max3_f32 %2, %10, %11, %12\n\t"
+          "v_max3_f32 %3, %13, %14, %15"
+          : "=&v"(mxa), "=&v"(mxb), "=&v"(mxc), "=&v"(mxd)
+          : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][8]), "v"(s[0][9]), "v"(s[0][10]), "v"(s[1][0]),
+            "v"(s[1][1]), "v"(s[1][2]), "v"(s[1][8]), "v"(s[1][9]), "v"(s[1][10]));
+      mxa = max3f(mxa, s[0][3], s[0][4]); mxb = max3f(mxb, s[0][11], s[0][12]);
+      mxc = max3f(mxc, s[1][3], s[1][4]); mxd = max3f(mxd, s[1][11], s[1][12]);
+      mxa = max3f(mxa, s[0][5], s[0][6]); mxb = max3f(mxb, s[0][13], s[0][14]);
+      mxc = max3f(mxc, s[1][5], s[1][6]); mxd = max3f(mxd, s[1][13], s[1][14]);
+      mxa = max3f(mxa, s[0][7], s[0][15]); mxc = max3f(mxc, s[1][7], s[1][15]);
+      float mx = max3f(mxa, mxb, mxc);
+      mx = xhalf_max(fmaxf(mx, mxd));
+      const bool move = (t == 0) || mx > 24.0f;
+      if (__builtin_amdgcn_ballot_w64(move) != 0) {
+        const float m_new = move ? bf16_ceil(m_run + mx) : m_run;
+        const float delta = m_new - m_run;  // exact: both are bf16 values
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        m_run = m_new;
+        if (h == MREF_HALF) {  // refresh the -m_ref slot of this lane's Q fragment
+          Vec16<T> v;
+          v.u = qf[MREF_STEP];
+          v.e[MREF_ELEM] = from_f32<T>(-m_new);
+          qf[MREF_STEP] = v.u;
+        }
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r]);
+    // ---- O^T += V^T P^T ----
+    {
+      const unsigned va0 = vaddr0 + bo + vh0, va1 = vaddr0 + bo + vh1;
+#define AF_PV_STEP(KB, S2)                                                                                           \
+      {                                                                                                              \
+        constexpr int RO = ((KB) * 32 + (S2) * 16) * VROW;                                                           \
+        u32x2 lo0 = lds_read_tr64<RO>(va0), hi0 = lds_read_tr64<RO + 8 * VROW>(va0);                                 \
+        u32x2 lo1 = lds_read_tr64<RO>(va1), hi1 = lds_read_tr64<RO + 8 * VROW>(va1);                                 \
+        Vec16<T> pb;                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) pb.e[j] = from_f32<T>(s[KB][8 * (S2) + j]);                    \
+        wait_lgkm2<2>(lo0, hi0);                                                                                     \
+        mma(u32x4{lo0.x, lo0.y, hi0.x, hi0.y}, pb.u, o[0]);                                                          \
+        wait_lgkm2<0>(lo1, hi1);                                                                                     \
+        mma(u32x4{lo1.x, lo1.y, hi1.x, hi1.y}, pb.u, o[1]);                                                          \
+      }
+      AF_PV_STEP(0, 0) AF_PV_STEP(0, 1) AF_PV_STEP(1, 0) AF_PV_STEP(1, 1)
+#undef AF_PV_STEP
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of tile t+1 landed
+    __builtin_amdgcn_s_barrier();                      // everyone's pieces landed; everyone is done reading tile t
+  }
+  // row DH of O^T (the ones column): block DH/32, in-block row rr -> register (rr&3)+4*(rr>>3) of lane-half (rr>>2)&1
+  constexpr int rr = DH % 32, ob = DH / 32, oreg = (rr & 3) + 4 * (rr >> 3), oh = (rr >> 2) & 1;
+  const float l_tot = __shfl(o[ob][oreg], l31 + 32 * oh, 64);
+  const float inv = 1.0f / l_tot;
+  bool bad = !(l_tot > 0.f && l_tot < INFINITY);
+  if (p.lse && q_ok && h == 0)
+    p.lse[((long)blockIdx.z * p.H + blockIdx.y) * p.Nq + q] = m_run + __builtin_amdgcn_logf(l_tot);
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dd = 32 * d + 8 * g + 4 * h;
+      if (dd < DH) {
+        Quad<T> ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float val = o[d][4 * g + e] * inv;
+          bad = bad || !(fabsf(val) < INFINITY);
+          ov.e[e] = from_f32<T>(val);
+        }
+        if (q_ok) ov.store(O + (long)q * p.ldo + dd);
+      }
+    }
+  return bad && q_ok;
+}
+
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_ring40_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const bool bad = pass<false>(p, smem);
+  // (every DMA has been waited for and the last tile's barrier passed: LDS is free again)
+  if (__syncthreads_or(bad ? 1 : 0)) pass<true>(p, smem);
+}
+}  // namespace ring40
+
 template <typename T, int DH> __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) { attn_body<T, DH>(p); }
 // dh = 40 (the 64x64 self-attention, 16 % of a denoising step): 132 VGPRs as written; capped at 128 the kernel runs
 // four waves per SIMD instead of three (LDS allows four workgroups per CU)
@@ -377,6 +661,15 @@ template <typename T, int DH> static int launch_attn(const AttnParams& p, int B,
   static unsigned long long attr_done = 0, attr_done_w4 = 0;
   if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&attn_kernel<T, DH>), C::LDS_BYTES)) return rc;
   if (int rc = af_ensure_dynamic_lds(attr_done_w4, reinterpret_cast<const void*>(&attn_kernel_w4<T, DH>), C::LDS_BYTES)) return rc;
+  if constexpr (C::BF && DH == 40) {
+    if (g_af_knobs.attn_ring) {   // eight-wave LDS-DMA ring kernel (the 64x64 level)
+      static unsigned long long attr_done_ring = 0;
+      if (int rc = af_ensure_dynamic_lds(attr_done_ring, reinterpret_cast<const void*>(&ring40::attn_ring40_kernel), ring40::LDS_BYTES)) return rc;
+      hipLaunchKernelGGL(ring40::attn_ring40_kernel, dim3((p.Nq + 255) / 256, p.H, B), dim3(ring40::NT), ring40::LDS_BYTES, stream, p);
+      HIP_CHECK_RET(hipGetLastError());
+      return 0;
+    }
+  }
   dim3 grid((p.Nq + 127) / 128, p.H, B);
   if (C::BF && DH == 40 && g_af_knobs.attn_w4)
     hipLaunchKernelGGL((attn_kernel_w4<T, DH>), grid, dim3(256), C::LDS_BYTES, stream, p);

@@ -77,6 +77,7 @@ struct AfKnobs {
   int gemm_dma;             // AF_GEMM_DMA             0 / 1: force register / LDS-DMA staging in the four-wave kernel
   int pp_direct;            // AF_PP_DIRECT            0 / 1: force the LDS / direct epilogue of the ping-pong kernel
   int attn_w4;              // AF_ATTN_W4              0 = dh-40 attention without the four-waves-per-SIMD cap
+  int attn_ring;            // AF_ATTN_RING            0 = dh-40 bf16 attention on the four-wave kernel instead of the ring kernel
   int gn_small;             // AF_GN_SMALL             0 = no single-launch GroupNorm for small maps
   int gn_fold;              // AF_GN_FOLD              0 = separate GroupNorm finalize pass
 };

@@ -50,15 +50,15 @@ AfKnobs g_af_knobs = {
     knob_env("AF_SPLITK_TARGET", 320), knob_env("AF_CONV_HALO", 1),       knob_env("AF_GEMM_PP", 1),
     knob_env("AF_GEMM_PP_GEGLU_MINKT", 0), knob_env("AF_GEMM_PP_MINFILL", 50), knob_env("AF_GEMM_TILE", -1),
     knob_env("AF_GEMM_SPLITK", -1),    knob_env("AF_GEMM_GROUPM", -1),    knob_env("AF_GEMM_DMA", -1),
-    knob_env("AF_PP_DIRECT", -1),      knob_env("AF_ATTN_W4", 1),         knob_env("AF_GN_SMALL", 1),
-    knob_env("AF_GN_FOLD", 1)};
+    knob_env("AF_PP_DIRECT", -1),      knob_env("AF_ATTN_W4", 1),         knob_env("AF_ATTN_RING", 1),
+    knob_env("AF_GN_SMALL", 1),        knob_env("AF_GN_FOLD", 1)};
 static const AfKnobs g_af_knobs_initial = g_af_knobs;
 static int* knob_slot(const char* name) {
   static const struct { const char* n; int AfKnobs::*m; } tab[] = {
       {"splitk_target", &AfKnobs::splitk_target}, {"conv_halo", &AfKnobs::conv_halo}, {"gemm_pp", &AfKnobs::gemm_pp},
       {"gemm_pp_geglu_minkt", &AfKnobs::gemm_pp_geglu_minkt}, {"gemm_pp_minfill", &AfKnobs::gemm_pp_minfill},
       {"gemm_tile", &AfKnobs::gemm_tile}, {"gemm_splitk", &AfKnobs::gemm_splitk}, {"gemm_groupm", &AfKnobs::gemm_groupm},
-      {"gemm_dma", &AfKnobs::gemm_dma}, {"pp_direct", &AfKnobs::pp_direct}, {"attn_w4", &AfKnobs::attn_w4},
+      {"gemm_dma", &AfKnobs::gemm_dma}, {"pp_direct", &AfKnobs::pp_direct}, {"attn_w4", &AfKnobs::attn_w4}, {"attn_ring", &AfKnobs::attn_ring},
       {"gn_small", &AfKnobs::gn_small}, {"gn_fold", &AfKnobs::gn_fold}};
   if (!name) return nullptr;
   for (auto& t : tab)
