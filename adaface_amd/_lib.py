@@ -122,14 +122,14 @@ def reset_knobs() -> None:
 
 
 def plan_counts(reset: bool = False) -> dict:
-    """af_gemm_plan_counts as a dict: tile0..tile5, halo, splitk."""
+    """af_gemm_plan_counts as a dict: tile0..tile5, halo, splitk, ln_consumer, ln_producer."""
     lib = load()
-    c = (C.c_int64 * 8)()
+    c = (C.c_int64 * 10)()
     check(lib.af_gemm_plan_counts(c), "af_gemm_plan_counts")
     if reset:
         lib.af_gemm_plan_counts_reset()
     out = {f"tile{i}": int(c[i]) for i in range(6)}
-    out["halo"], out["splitk"] = int(c[6]), int(c[7])
+    out["halo"], out["splitk"], out["ln_consumer"], out["ln_producer"] = int(c[6]), int(c[7]), int(c[8]), int(c[9])
     return out
 
 

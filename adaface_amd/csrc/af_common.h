@@ -80,6 +80,7 @@ struct AfKnobs {
   int attn_ring;            // AF_ATTN_RING            0 = dh-40 bf16 attention on the four-wave kernel instead of the ring kernel
   int gn_small;             // AF_GN_SMALL             0 = no single-launch GroupNorm for small maps
   int gn_fold;              // AF_GN_FOLD              0 = separate GroupNorm finalize pass
+  int ln_fuse;              // AF_LN_FUSE              0 = stand-alone LayerNorm kernels in front of the transformer GEMMs
 };
 extern AfKnobs g_af_knobs;
 
@@ -141,6 +142,15 @@ __device__ __forceinline__ float erf_as_f(float x) {
 }
 __device__ __forceinline__ float gelu_erf_f(float x) {
   return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f));
+}
+// GELU for bf16 OUTPUTS: x * Phi(x) with Phi(x) ~ sigmoid(x (a + b x^2)), (a, b) = (1.5974834, 0.0706872) fitted to the
+// exact erf form: |error| <= 4.0e-4 for every x (largest near |x| = 2.8, where one bf16 step of the result is 1.6e-2;
+// the small-|x| series agrees to 1e-3 of the quadratic term).  4 plain VALU + v_exp + v_rcp instead of 14 + 2: the
+// GEGLU epilogue of the ping-pong kernel evaluates it 16384 times per tile and is VALU-bound at K = 320.  The f32
+// (parity) kernels keep gelu_erf_f.
+__device__ __forceinline__ float gelu_bf16out_f(float x) {
+  const float u = x * fmaf(x * x, -0.07068715223f * 1.44269504089f, -1.59748341624f * 1.44269504089f);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
 }
 
 // ---------------------------------------------------------------------------
@@ -213,6 +223,18 @@ struct ConvGemmParams {
   void* ws;
   int group_m;            // grouped tile ordering (set by the launcher): M tiles swept per N tile
   int howo_shift, wo_shift;  // log2(Ho*Wo), log2(Wo) when they are powers of two, else -1 (set by the launcher)
+  // LayerNorm folded into the ping-pong GEMM (bf16, af_model.hip run_xfmr):
+  //   producer side: ln_stats_out != null -> besides its output the GEMM writes, per output row m and per 80-column slab
+  //     part = 2 * (n tile) + wave group, the sum and the sum of squares of the bf16-ROUNDED values it stored:
+  //     ln_stats_out[(part * M + m) * 2 + {0, 1}]  (fp32; fixed summation order, no atomics: deterministic)
+  //   consumer side: ln_stats != null -> the A operand is the un-normalised x and W holds W * gamma; the epilogue applies
+  //     out = rstd[m] * (acc - mu[m] * ln_colsum[n]) + bias[n] with mu / rstd from the ln_parts partial sums of row m
+  //     (ln_count = normalised width C) and bias = W beta + b precomputed at load time.  GEGLU composes with it.
+  float* ln_stats_out;
+  const float* ln_stats;
+  const float* ln_colsum;
+  int ln_parts;
+  float ln_inv_count, ln_eps;
   int pp_epilogue;        // ping-pong kernel (set by the launcher): 0 = direct for GEGLU / split-K slabs and LDS
                           // otherwise, 1 = always through LDS, 2 = always direct
 };

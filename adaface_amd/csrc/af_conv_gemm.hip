@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
               float val = acc[ni][mi][4 * q + e] * p.alpha;
               float gat = acc[ni][mi][4 * (q + 2) + e] * p.alpha;
               if (p.bias) { val += p.bias[nv + e]; gat += p.bias[nv + 16 + e]; }
-              op[e] = val * gelu_erf_f(gat);
+              op[e] = val * (sizeof(T) == 2 ? gelu_bf16out_f(gat) : gelu_erf_f(gat));
             }
             *reinterpret_cast<float4*>(et + row * C::EPI_LD + wn * 32 + ni * 16 + j) = o;
           }
@@ -485,7 +485,9 @@ __device__ __forceinline__ void pp_wait_lgkm0() {
   __builtin_amdgcn_sched_barrier(0);   // hipcc hoists register-only MFMAs over an asm wait without this
 }
 
-template <int BN, bool GATHER>
+// LNMODE: 0 = plain, 1 = LayerNorm consumer (A = un-normalised rows, epilogue applies mu / rstd), 2 = LayerNorm-statistics
+// producer (direct epilogue + per-row partial sums); separate instantiations so that the plain kernel's code is untouched
+template <int BN, bool GATHER, int LNMODE = 0>
 __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams p) {
   using C = PpCfg<BN>;
   typedef bf16 T;
@@ -641,6 +643,30 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     if (p.bias && p.splitk <= 1) bias_r[i] = *reinterpret_cast<const float4*>(p.bias + n0 + g * C::HN + i * 16 + cl);
   }
 
+  // LayerNorm consumer: column sums of W * gamma for this lane's channels and mu / rstd of its four rows
+  float4 ln_cs[LNMODE == 1 ? NI : 1];
+  float ln_mu[LNMODE == 1 ? MI : 1], ln_rs[LNMODE == 1 ? MI : 1];
+  if constexpr (LNMODE == 1) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) ln_cs[i] = *reinterpret_cast<const float4*>(p.ln_colsum + n0 + g * C::HN + i * 16 + cl);
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int m = m0 + wq * 64 + j * 16 + (lane & 15);
+      float s1 = 0.f, s2 = 0.f;
+      if (m < p.M) {
+        for (int part = 0; part < p.ln_parts; ++part) {   // fixed order: deterministic
+          const float2 st = *reinterpret_cast<const float2*>(p.ln_stats + ((long)part * p.M + m) * 2);
+          s1 += st.x;
+          s2 += st.y;
+        }
+      }
+      const float mu = s1 * p.ln_inv_count;
+      const float var = fmaxf(s2 * p.ln_inv_count - mu * mu, 0.f);
+      ln_mu[j] = mu;
+      ln_rs[j] = __builtin_amdgcn_rsqf(var + p.ln_eps);
+    }
+  }
+
   // ---- prologue: tile 0 (group 1 also tile 1) in flight; group 1's part of tile 0 landed ----
   stage(0);
   if (g == 1) {
@@ -695,9 +721,15 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
         for (int j = 0; j < MI; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float val = acc[2 * k2][j][e] * p.alpha + bvp[e];
-            const float gat = acc[2 * k2 + 1][j][e] * p.alpha + bgp[e];
-            acc[k2][j][e] = val * gelu_erf_f(gat);   // block k2 <= 2 k2: already consumed
+            float val, gat;
+            if constexpr (LNMODE == 1) {
+              val = (acc[2 * k2][j][e] - ln_mu[j] * reinterpret_cast<const float*>(&ln_cs[2 * k2])[e]) * ln_rs[j] + bvp[e];
+              gat = (acc[2 * k2 + 1][j][e] - ln_mu[j] * reinterpret_cast<const float*>(&ln_cs[2 * k2 + 1])[e]) * ln_rs[j] + bgp[e];
+            } else {
+              val = acc[2 * k2][j][e] * p.alpha + bvp[e];
+              gat = acc[2 * k2 + 1][j][e] * p.alpha + bgp[e];
+            }
+            acc[k2][j][e] = val * gelu_bf16out_f(gat);   // block k2 <= 2 k2: already consumed
           }
       }
     }
@@ -708,7 +740,12 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
 #pragma unroll
       for (int j = 0; j < MI; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][j][e] = acc[i][j][e] * p.alpha + bp[e];
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (LNMODE == 1)
+            acc[i][j][e] = (acc[i][j][e] - ln_mu[j] * reinterpret_cast<const float*>(&ln_cs[i])[e]) * ln_rs[j] + bp[e];
+          else
+            acc[i][j][e] = acc[i][j][e] * p.alpha + bp[e];
+        }
     }
   }
   const int BNo = geglu ? BN / 2 : BN;              // columns of the staged tile
@@ -720,7 +757,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
   const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
   const T* __restrict__ rowb = reinterpret_cast<const T*>(p.rowbias);
   float* slab = p.splitk > 1 ? reinterpret_cast<float*>(p.ws) + (long)zk * p.M * p.N : nullptr;
-  if (p.pp_epilogue == 2 || (p.pp_epilogue == 0 && (geglu || slab))) {
+  if (LNMODE == 2 || p.pp_epilogue == 2 || (p.pp_epilogue == 0 && (geglu || slab))) {
     // Direct epilogue: every lane stores its 4 consecutive output channels of a pixel straight from the accumulator
     // (8-byte stores, four lanes covering a 32-byte run of the row; fp32 split-K slabs: 16-byte stores).  No LDS pass,
     // no workgroup barriers; the time-bias / residual quads of a row group are fetched before its first store.
@@ -731,6 +768,42 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
       const int m = m0 + wq * 64 + j * 16 + (lane & 15);
+      if constexpr (LNMODE == 2) {
+        // statistics producer: every lane takes part in the row reduction, rows >= M contribute nothing and store nothing
+        const bool mok = m < p.M;
+        Quad<T> rq[NI], bq[NI];
+        if (rowb && mok) {
+          const T* rp = rowb + (long)(p.howo_shift >= 0 ? m >> p.howo_shift : m / HoWo) * p.ldrb + cbase;
+#pragma unroll
+          for (int i = 0; i < NI; ++i) bq[i].load(rp + i * 16);
+        }
+        if (res && mok) {
+          const T* rp = res + (long)m * p.ldr + cbase;
+#pragma unroll
+          for (int i = 0; i < NI; ++i) rq[i].load(rp + i * 16);
+        }
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          Quad<T> o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][j][e];
+            if (rowb && mok) v += to_f32<T>(bq[i].e[e]);
+            if (res && mok) v += to_f32<T>(rq[i].e[e]);
+            o.e[e] = from_f32<T>(v);
+            const float vr = to_f32<T>(o.e[e]);   // the value the consumer will read
+            ps += vr;
+            pq += vr * vr;
+          }
+          if (mok) o.store(out + (long)m * p.ldo + cbase + i * 16);
+        }
+        ps += __shfl_xor(ps, 16, 64); pq += __shfl_xor(pq, 16, 64);
+        ps += __shfl_xor(ps, 32, 64); pq += __shfl_xor(pq, 32, 64);
+        if (mok && (lane >> 4) == 0)
+          *reinterpret_cast<float2*>(p.ln_stats_out + ((long)(tn * 2 + g) * p.M + m) * 2) = float2{ps, pq};
+        continue;
+      }
       if (m >= p.M) continue;
       if (slab) {
 #pragma unroll
@@ -1109,8 +1182,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvGemmParams
 // ---------------------------------------------------------------------------
 AfGemmPlan g_af_last_plan = {0, 1, 0, 0, 1};
 // launches since af_gemm_plan_counts_reset: [0..5] by tile (implicit-GEMM / ping-pong kernels), [6] LDS-halo kernel,
-// [7] launches that sliced K (counted in their tile's slot as well)
-long g_af_plan_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// [7] launches that sliced K (counted in their tile's slot as well), [8] / [9] ping-pong launches with the LayerNorm
+// consumer / statistics-producer epilogue
+long g_af_plan_counts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 
 // tile: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64
@@ -1250,11 +1324,21 @@ static int launch_cfg(const ConvGemmParams& p, int batch, hipStream_t stream) {
 template <int BN> static int launch_pp(const ConvGemmParams& p, hipStream_t stream) {
   using C = PpCfg<BN>;
   const bool gather = !(p.ks == 1 && p.pad == 0);
-  static unsigned long long attr_done_g = 0, attr_done_p = 0;
+  static unsigned long long attr_done_g = 0, attr_done_p = 0, attr_done_c = 0, attr_done_s = 0;
   if (int rc = af_ensure_dynamic_lds(attr_done_g, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, true>), C::LDS_BYTES)) return rc;
   if (int rc = af_ensure_dynamic_lds(attr_done_p, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, false>), C::LDS_BYTES)) return rc;
+  if (int rc = af_ensure_dynamic_lds(attr_done_c, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, false, 1>), C::LDS_BYTES)) return rc;
+  if (int rc = af_ensure_dynamic_lds(attr_done_s, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, false, 2>), C::LDS_BYTES)) return rc;
   dim3 grid(((p.M + 255) / 256) * (p.N / BN), 1, p.splitk > 1 ? p.splitk : 1);
-  if (gather) hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, true>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  if (p.ln_stats || p.ln_stats_out) {
+    // LayerNorm-fused variants: plain (1x1) GEMMs on one K slice only; the caller (af_model.hip) asks the planner first
+    if (gather || p.splitk > 1 || (p.ln_stats && p.ln_stats_out) || (p.ln_stats_out && p.epilogue == AF_EPI_GEGLU)) {
+      af_set_error_msg("conv_gemm: LayerNorm-fused launch needs a 1x1 GEMM without split-K");
+      return -1;
+    }
+    if (p.ln_stats) hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, false, 1>), grid, dim3(512), C::LDS_BYTES, stream, p);
+    else hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, false, 2>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  } else if (gather) hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, true>), grid, dim3(512), C::LDS_BYTES, stream, p);
   else hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, false>), grid, dim3(512), C::LDS_BYTES, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
@@ -1307,6 +1391,8 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   g_af_last_plan = pl;
   g_af_plan_counts[pl.halo_tw ? 6 : (pl.tile >= 0 && pl.tile < 6 ? pl.tile : 0)] += 1;
   if (pl.splitk > 1) g_af_plan_counts[7] += 1;
+  if (p.ln_stats) g_af_plan_counts[8] += 1;
+  if (p.ln_stats_out) g_af_plan_counts[9] += 1;
   {
     auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (v > 0 && (1 << s) == v) ? s : -1; };
     p.howo_shift = lg2(p.Ho * p.Wo);
@@ -1319,6 +1405,10 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   AfProfScope prof(prof_cls, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K) * batch,
                    ((double)p.M * p.K / (p.ks * p.ks) + (double)p.N * p.K + (double)p.M * p.N) * batch * sizeof(T));
   int rc;
+  if ((p.ln_stats || p.ln_stats_out) && !(pl.tile >= 4 && !pl.halo_tw)) {
+    af_set_error_msg("conv_gemm: LayerNorm-fused launch planned on a kernel without that epilogue (tile %d)", pl.tile);
+    return -1;
+  }
   if (pl.halo_tw) {
     const bool bn128 = pl.tile == 0 || pl.tile == 1;
     if (pl.halo_tw == 32) rc = bn128 ? launch_halo<T, 32, 128>(p, stream) : launch_halo<T, 32, 64>(p, stream);

@@ -503,6 +503,37 @@ int af_launch_repack_weight(const float* src, void* dst, int rows, int cin, int 
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+// LayerNorm folded into the following linear (ping-pong GEMM, LNMODE 1):  LN(x) W^T + b
+//   = rstd * (x (W gamma)^T - mu * colsum) + (W beta + b)   with colsum[n] = sum_k (W gamma)[n][k].
+// One wave per weight row: Wf[n][k] = T(W[n][k] * gamma[k]); colsum from the ROUNDED products (what the MFMA multiplies).
+template <typename T>
+__global__ void ln_fold_kernel(const T* __restrict__ W, T* __restrict__ Wf, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ bias, float* __restrict__ colsum,
+                               float* __restrict__ biasf, int rows, int K, int ldw) {
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= rows) return;
+  float cs = 0.f, bs = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = to_f32<T>(W[(long)n * ldw + k]);
+    const T wf = from_f32<T>(w * gamma[k]);
+    Wf[(long)n * ldw + k] = wf;
+    cs += to_f32<T>(wf);
+    bs += w * beta[k];
+  }
+  for (int o = 32; o > 0; o >>= 1) { cs += __shfl_xor(cs, o, 64); bs += __shfl_xor(bs, o, 64); }
+  if (lane == 0) { colsum[n] = cs; biasf[n] = bs + (bias ? bias[n] : 0.f); }
+}
+template <typename T>
+int af_launch_ln_fold(const void* W, void* Wf, const float* gamma, const float* beta, const float* bias, float* colsum,
+                      float* biasf, int rows, int K, int ldw, hipStream_t s) {
+  hipLaunchKernelGGL((ln_fold_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, reinterpret_cast<const T*>(W),
+                     reinterpret_cast<T*>(Wf), gamma, beta, bias, colsum, biasf, rows, K, ldw);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template int af_launch_ln_fold<bf16>(const void*, void*, const float*, const float*, const float*, float*, float*, int, int, int, hipStream_t);
+template int af_launch_ln_fold<float>(const void*, void*, const float*, const float*, const float*, float*, float*, int, int, int, hipStream_t);
+
 int af_launch_permute_bias(const float* src, float* dst, int rows, int perm, hipStream_t s) {
   hipLaunchKernelGGL(permute_bias_kernel, EW_GRID(rows), dim3(256), 0, s, src, dst, rows, perm);
   HIP_CHECK_RET(hipGetLastError());

@@ -55,7 +55,11 @@ template <typename T>
 int af_launch_repack_weight(const float* src, void* dst, int rows, int cin, int cin_pad, int ks, int ldw, int row_off,
                             int perm, hipStream_t s);
 int af_launch_permute_bias(const float* src, float* dst, int rows, int perm, hipStream_t s);
+// LayerNorm folded into a linear: Wf = W * gamma (rounded to T), colsum[n] = sum_k Wf[n][k], biasf = W beta + bias
+template <typename T>
+int af_launch_ln_fold(const void* W, void* Wf, const float* gamma, const float* beta, const float* bias, float* colsum,
+                      float* biasf, int rows, int K, int ldw, hipStream_t s);
 
 // plan of the most recent af_launch_conv_gemm (diagnostics, af_last_gemm_plan)
 extern AfGemmPlan g_af_last_plan;
-extern long g_af_plan_counts[8];
+extern long g_af_plan_counts[10];

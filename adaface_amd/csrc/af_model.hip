@@ -51,7 +51,7 @@ AfKnobs g_af_knobs = {
     knob_env("AF_GEMM_PP_GEGLU_MINKT", 0), knob_env("AF_GEMM_PP_MINFILL", 50), knob_env("AF_GEMM_TILE", -1),
     knob_env("AF_GEMM_SPLITK", -1),    knob_env("AF_GEMM_GROUPM", -1),    knob_env("AF_GEMM_DMA", -1),
     knob_env("AF_PP_DIRECT", -1),      knob_env("AF_ATTN_W4", 1),         knob_env("AF_ATTN_RING", 1),
-    knob_env("AF_GN_SMALL", 1),        knob_env("AF_GN_FOLD", 1)};
+    knob_env("AF_GN_SMALL", 1),        knob_env("AF_GN_FOLD", 1),         knob_env("AF_LN_FUSE", 1)};
 static const AfKnobs g_af_knobs_initial = g_af_knobs;
 static int* knob_slot(const char* name) {
   static const struct { const char* n; int AfKnobs::*m; } tab[] = {
@@ -59,7 +59,7 @@ static int* knob_slot(const char* name) {
       {"gemm_pp_geglu_minkt", &AfKnobs::gemm_pp_geglu_minkt}, {"gemm_pp_minfill", &AfKnobs::gemm_pp_minfill},
       {"gemm_tile", &AfKnobs::gemm_tile}, {"gemm_splitk", &AfKnobs::gemm_splitk}, {"gemm_groupm", &AfKnobs::gemm_groupm},
       {"gemm_dma", &AfKnobs::gemm_dma}, {"pp_direct", &AfKnobs::pp_direct}, {"attn_w4", &AfKnobs::attn_w4}, {"attn_ring", &AfKnobs::attn_ring},
-      {"gn_small", &AfKnobs::gn_small}, {"gn_fold", &AfKnobs::gn_fold}};
+      {"gn_small", &AfKnobs::gn_small}, {"gn_fold", &AfKnobs::gn_fold}, {"ln_fuse", &AfKnobs::ln_fuse}};
   if (!name) return nullptr;
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) return &(g_af_knobs.*(t.m));
@@ -166,6 +166,9 @@ struct ResBlockW {
 struct XfmrBlockW {
   Norm ln1, ln2, ln3;
   Linear qkv1, out1, q2, kv2, out2, ff1, ff2;
+  // LayerNorm folded into the consumer GEMM (bf16 mode): W * gamma, bias = W beta + b, column sums of W * gamma
+  Linear qkv1_ln, q2_ln, ff1_ln;
+  float *qkv1_cs = nullptr, *q2_cs = nullptr, *ff1_cs = nullptr;
 };
 struct XfmrW {
   int C = 0, heads = 0, dh = 0;
@@ -249,6 +252,8 @@ struct af_handle {
   std::vector<int> conv_tokens;   // [conv_batch.size()][9]
   int* ctx_rowmap = nullptr;      // device row map used by set_context when conv attention is on
   size_t ctx_rowmap_n = 0;
+
+  bool ln_fold_dirty = true;   // folded LayerNorm twins must be recomputed (a UNet tensor was loaded since)
 
   // diagnostic tap (af_unet_set_tap): block whose output the next forwards also write, fp32 NCHW
   int tap_index = -1;
@@ -398,6 +403,17 @@ static int make_xfmr(Builder& b, const std::string& prefix, int C, int heads, in
     t.ff1.bias = b.alloc_vec(8 * inner);
     b.vec_slot(p + ".ff.net.0.proj.bias", t.ff1.bias, 8 * inner, 1);
     b.make_conv(t.ff2, p + ".ff.net.2", 4 * inner, inner, 1, true, false);
+    if (h->dtype == AF_DTYPE_BF16) {   // folded twins (filled by fold_layernorms once every tensor is loaded)
+      auto twin = [&](const Linear& src, Linear& dst, float*& cs) {
+        dst = src;
+        dst.w = b.dmalloc((size_t)src.rows_pad * src.ldw * esize(h->dtype));
+        dst.bias = b.alloc_vec(src.rows_pad);
+        cs = b.alloc_vec(src.rows_pad);
+      };
+      twin(t.qkv1, t.qkv1_ln, t.qkv1_cs);
+      twin(t.q2, t.q2_ln, t.q2_cs);
+      twin(t.ff1, t.ff1_ln, t.ff1_cs);
+    }
     x.blocks.push_back(t);
   }
   b.make_conv(x.proj_out, prefix + ".proj_out", inner, C, 1);
@@ -673,10 +689,13 @@ struct Runner {
   // pad < 0: the layer's symmetric ks/2.  pad = 0 with stride 2 on an even map is the VAE Downsample: the reference
   // pads one zero row / column at the bottom / right only (model.py:73-77), which is exactly what the gather's
   // bounds check returns for iy == Hi / ix == Wi
-  int conv(const Linear& L, const Act& x, Act& out, int stride, int up, const Act* residual, const void* rowbias,
-           int ldrb, int n_valid = -1, int pad = -1) {
-    AF_TRY(check(out));
-    ConvGemmParams p;
+  // LayerNorm folded into a ping-pong GEMM (ConvGemmParams::ln_*): consumer (stats + colsum) or producer (stats_out)
+  struct LnArgs {
+    const float* stats = nullptr; int parts = 0; const float* colsum = nullptr; float eps = 1e-5f; int count = 0;
+    float* stats_out = nullptr;
+  };
+  void conv_params(ConvGemmParams& p, const Linear& L, const Act& x, const Act& out, int stride, int up,
+                   const Act* residual, const void* rowbias, int ldrb, int n_valid, int pad) const {
     memset(&p, 0, sizeof(p));
     p.src = x.p;
     p.src_batch_stride = (long)x.H * x.W * x.ld;
@@ -699,6 +718,27 @@ struct Runner {
     p.out = out.p; p.ldo = out.ld;
     p.epilogue = L.geglu ? AF_EPI_GEGLU : AF_EPI_NONE;
     p.alpha = 1.0f;
+  }
+  // would this 1x1 GEMM run on the ping-pong kernel in one K slice (the only place the LayerNorm epilogues exist)?
+  // returns the number of 80-column statistics slabs its output rows would be cut into (0 = no)
+  int ln_capable(const Linear& L, const Act& x, const Act& out, int n_valid = -1) const {
+    if (dt != AF_DTYPE_BF16 || L.ks != 1) return 0;
+    ConvGemmParams p;
+    conv_params(p, L, x, out, 1, 0, nullptr, nullptr, 0, n_valid, -1);
+    const AfGemmPlan pl = af_plan_conv_gemm(p, 1, (int)esize(dt));
+    if (pl.tile < 4 || pl.splitk > 1 || pl.halo_tw) return 0;
+    return (p.N / (pl.tile == 5 ? 160 : 128)) * 2;
+  }
+  int conv(const Linear& L, const Act& x, Act& out, int stride, int up, const Act* residual, const void* rowbias,
+           int ldrb, int n_valid = -1, int pad = -1, const LnArgs* ln = nullptr) {
+    AF_TRY(check(out));
+    ConvGemmParams p;
+    conv_params(p, L, x, out, stride, up, residual, rowbias, ldrb, n_valid, pad);
+    if (ln) {
+      p.ln_stats = ln->stats; p.ln_parts = ln->parts; p.ln_colsum = ln->colsum; p.ln_eps = ln->eps;
+      p.ln_inv_count = ln->count > 0 ? 1.0f / (float)ln->count : 0.f;
+      p.ln_stats_out = ln->stats_out;
+    }
     if (x.C < L.cin || x.ld < L.cin_pad) {
       af_set_error_msg("conv: input has %d channels (ld %d), layer expects %d (padded %d)", x.C, x.ld, L.cin, L.cin_pad);
       return AF_ERR_INVALID;
@@ -789,24 +829,65 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out) {
   Act g = R.alloc_act(B, H, W, x.C);
   AF_TRY(R.groupnorm(w.gn, x, g, 0));
   Act t = R.alloc_act(B, H, W, C);
-  AF_TRY(R.conv(w.proj_in, g, t, 1, 0, nullptr, nullptr, 0));
+  // LayerNorm folding (bf16): when every GEMM around the three LayerNorms of a block runs on the ping-pong kernel in
+  // one K slice, the producer of each normalised tensor also writes per-row partial sums and the consumer GEMM applies
+  // mu / rstd in its epilogue on W * gamma — the stand-alone LayerNorm passes (read + write of [M, C] each) disappear.
+  Act f_probe = t;
+  f_probe.C = 4 * C; f_probe.ld = 4 * C;
+  Act qkv_probe = t;
+  qkv_probe.C = 3 * C; qkv_probe.ld = 3 * C;
+  int ln_parts = 0;
+  if (g_af_knobs.ln_fuse && !w.blocks.empty() && w.blocks[0].qkv1_ln.w) {
+    const XfmrBlockW& b0 = w.blocks[0];
+    const int pp = R.ln_capable(w.proj_in, g, t);
+    const bool ok = pp > 0 && R.ln_capable(b0.out1, t, t) == pp && R.ln_capable(b0.out2, t, t) == pp &&
+                    R.ln_capable(b0.ff2, f_probe, t) == pp && R.ln_capable(b0.qkv1_ln, t, qkv_probe) > 0 &&
+                    R.ln_capable(b0.q2_ln, t, t) > 0 && R.ln_capable(b0.ff1_ln, t, f_probe, 8 * C) > 0;
+    if (ok) ln_parts = pp;
+  }
+  const size_t st_elems = (size_t)ln_parts * B * N * 2;
+  float* st_t = ln_parts ? reinterpret_cast<float*>(R.A.alloc(st_elems * sizeof(float))) : nullptr;    // stats of t
+  float* st_1 = ln_parts ? reinterpret_cast<float*>(R.A.alloc(st_elems * sizeof(float))) : nullptr;    // ... of t1
+  float* st_2 = ln_parts ? reinterpret_cast<float*>(R.A.alloc(st_elems * sizeof(float))) : nullptr;    // ... of t2
+  if (ln_parts && !st_2) { af_set_error_msg("arena exhausted (LayerNorm statistics)"); return AF_ERR_STATE; }
+  auto producer = [&](float* st) { Runner::LnArgs a; a.stats_out = st; return a; };
+  auto consumer = [&](const float* st, const float* cs, const Norm& ln) {
+    Runner::LnArgs a; a.stats = st; a.parts = ln_parts; a.colsum = cs; a.eps = ln.eps; a.count = C; return a;
+  };
+  {
+    const Runner::LnArgs pa = producer(st_t);
+    AF_TRY(R.conv(w.proj_in, g, t, 1, 0, nullptr, nullptr, 0, -1, -1, ln_parts ? &pa : nullptr));
+  }
   for (size_t d = 0; d < w.blocks.size(); ++d) {
     const XfmrBlockW& blk = w.blocks[d];
     const size_t mk2 = R.A.mark();
     // --- x = attn1(norm1(x)) + x ---
     Act n = R.alloc_act(B, H, W, C);
-    AF_TRY(R.layernorm(blk.ln1, t, n));
     Act qkv = R.alloc_act(B, H, W, 3 * C);
-    AF_TRY(R.conv(blk.qkv1, n, qkv, 1, 0, nullptr, nullptr, 0));
+    if (ln_parts) {
+      const Runner::LnArgs ca = consumer(st_t, blk.qkv1_cs, blk.ln1);
+      AF_TRY(R.conv(blk.qkv1_ln, t, qkv, 1, 0, nullptr, nullptr, 0, -1, -1, &ca));
+    } else {
+      AF_TRY(R.layernorm(blk.ln1, t, n));
+      AF_TRY(R.conv(blk.qkv1, n, qkv, 1, 0, nullptr, nullptr, 0));
+    }
     Act a = R.alloc_act(B, H, W, C);
     AF_TRY(R.attention(qkv.p, 3 * C, (long)N * 3 * C, R.elem_ptr(qkv.p, C), 3 * C, (long)N * 3 * C,
                        R.elem_ptr(qkv.p, 2 * C), 3 * C, (long)N * 3 * C, a, N, N, w.heads, w.dh));
     Act t1 = R.alloc_act(B, H, W, C);
-    AF_TRY(R.conv(blk.out1, a, t1, 1, 0, &t, nullptr, 0));
+    {
+      const Runner::LnArgs pa = producer(st_1);
+      AF_TRY(R.conv(blk.out1, a, t1, 1, 0, &t, nullptr, 0, -1, -1, ln_parts ? &pa : nullptr));
+    }
     // --- x = x + attn2(norm2(x), context) ---
-    AF_TRY(R.layernorm(blk.ln2, t1, n));
     Act q = R.alloc_act(B, H, W, C);
-    AF_TRY(R.conv(blk.q2, n, q, 1, 0, nullptr, nullptr, 0));
+    if (ln_parts) {
+      const Runner::LnArgs ca = consumer(st_1, blk.q2_cs, blk.ln2);
+      AF_TRY(R.conv(blk.q2_ln, t1, q, 1, 0, nullptr, nullptr, 0, -1, -1, &ca));
+    } else {
+      AF_TRY(R.layernorm(blk.ln2, t1, n));
+      AF_TRY(R.conv(blk.q2, n, q, 1, 0, nullptr, nullptr, 0));
+    }
     const CtxKV& kv = h->ctx_kv[w.ca_slot + d];
     const int S = h->ctx_tokens;
     if (!R.dry && (!kv.kv || h->ctx_Bf != B)) {
@@ -854,17 +935,46 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out) {
       R.A.release(mk3);
     }
     Act t2 = R.alloc_act(B, H, W, C);
-    AF_TRY(R.conv(blk.out2, a, t2, 1, 0, &t1, nullptr, 0));
+    {
+      const Runner::LnArgs pa = producer(st_2);
+      AF_TRY(R.conv(blk.out2, a, t2, 1, 0, &t1, nullptr, 0, -1, -1, ln_parts ? &pa : nullptr));
+    }
     // --- x = ff(norm3(x)) + x ---
-    AF_TRY(R.layernorm(blk.ln3, t2, n));
     Act f = R.alloc_act(B, H, W, 4 * C);
-    AF_TRY(R.conv(blk.ff1, n, f, 1, 0, nullptr, nullptr, 0, 8 * C));
-    // write the block output over `t` (its last reader was out1's residual)
-    AF_TRY(R.conv(blk.ff2, f, t, 1, 0, &t2, nullptr, 0));
+    if (ln_parts) {
+      const Runner::LnArgs ca = consumer(st_2, blk.ff1_cs, blk.ln3);
+      AF_TRY(R.conv(blk.ff1_ln, t2, f, 1, 0, nullptr, nullptr, 0, 8 * C, -1, &ca));
+    } else {
+      AF_TRY(R.layernorm(blk.ln3, t2, n));
+      AF_TRY(R.conv(blk.ff1, n, f, 1, 0, nullptr, nullptr, 0, 8 * C));
+    }
+    // write the block output over `t` (its last reader was out1's residual); a following block normalises it again
+    {
+      const Runner::LnArgs pa = producer(st_t);
+      AF_TRY(R.conv(blk.ff2, f, t, 1, 0, &t2, nullptr, 0, -1, -1, (ln_parts && d + 1 < w.blocks.size()) ? &pa : nullptr));
+    }
     R.A.release(mk2);
   }
   AF_TRY(R.conv(w.proj_out, t, out, 1, 0, &x, nullptr, 0));
   R.A.release(mk);
+  return 0;
+}
+
+// (re)compute the LayerNorm-folded twins of every transformer block from the loaded tensors
+static int fold_layernorms(af_handle* h, hipStream_t s) {
+  if (!h->ln_fold_dirty || h->dtype != AF_DTYPE_BF16) { h->ln_fold_dirty = false; return 0; }
+  for (auto& x : h->xf)
+    for (auto& t : x.blocks) {
+      if (!t.qkv1_ln.w) continue;
+      const int C = x.heads * x.dh;
+      AF_TRY(af_launch_ln_fold<bf16>(t.qkv1.w, t.qkv1_ln.w, t.ln1.gamma, t.ln1.beta, t.qkv1.bias, t.qkv1_cs, t.qkv1_ln.bias,
+                                     t.qkv1.rows_pad, C, t.qkv1.ldw, s));
+      AF_TRY(af_launch_ln_fold<bf16>(t.q2.w, t.q2_ln.w, t.ln2.gamma, t.ln2.beta, t.q2.bias, t.q2_cs, t.q2_ln.bias,
+                                     t.q2.rows_pad, C, t.q2.ldw, s));
+      AF_TRY(af_launch_ln_fold<bf16>(t.ff1.w, t.ff1_ln.w, t.ln3.gamma, t.ln3.beta, t.ff1.bias, t.ff1_cs, t.ff1_ln.bias,
+                                     t.ff1.rows_pad, C, t.ff1.ldw, s));
+    }
+  h->ln_fold_dirty = false;
   return 0;
 }
 
@@ -1326,6 +1436,7 @@ static int load_tensor_impl(af_handle* h, const char* name, const float* host_da
   }
   HIP_CHECK_RET(hipStreamSynchronize(0));
   s.loaded = true;
+  h->ln_fold_dirty = true;
   return 0;
 }
 
@@ -1456,6 +1567,7 @@ int af_unet_forward(af_handle* h, const float* x_dev, const int64_t* t_dev, floa
   if (H % down || W % down) { af_set_error_msg("af_unet_forward: H,W must be multiples of %d", down); return AF_ERR_INVALID; }
   HIP_CHECK_RET(hipSetDevice(h->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  AF_TRY(fold_layernorms(h, s));
   // size the arena with a dry run
   h->arena.dry = true; h->arena.peak = 0;
   int rc = unet_forward_impl(h, s, x_dev, t_dev, eps_dev, Bf, H, W);
@@ -1601,13 +1713,13 @@ int af_last_gemm_plan(int* tile, int* splitk, int* halo_tw) {
   if (halo_tw) *halo_tw = g_af_last_plan.halo_tw;
   return AF_OK;
 }
-int af_gemm_plan_counts(int64_t* counts8) {
-  if (!counts8) { af_set_error_msg("af_gemm_plan_counts: null argument"); return AF_ERR_INVALID; }
-  for (int i = 0; i < 8; ++i) counts8[i] = g_af_plan_counts[i];
+int af_gemm_plan_counts(int64_t* counts10) {
+  if (!counts10) { af_set_error_msg("af_gemm_plan_counts: null argument"); return AF_ERR_INVALID; }
+  for (int i = 0; i < 10; ++i) counts10[i] = g_af_plan_counts[i];
   return AF_OK;
 }
 int af_gemm_plan_counts_reset(void) {
-  for (int i = 0; i < 8; ++i) g_af_plan_counts[i] = 0;
+  for (int i = 0; i < 10; ++i) g_af_plan_counts[i] = 0;
   return AF_OK;
 }
 int af_prof_collect(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes) {

@@ -148,9 +148,10 @@ int af_prof_collect(int n_classes, double* ms, int64_t* launches, double* flops,
  * tile: 0-3 = 128x128 / 64x128 / 128x64 / 64x64 four-wave tiles, 4 / 5 = 256x128 / 256x160 eight-wave ping-pong tiles;
  * halo_tw != 0: LDS-halo 3x3 kernel.  The parity tests use it to assert which kernel they exercised. */
 int af_last_gemm_plan(int* tile, int* splitk, int* halo_tw);
-/* launches per tiling since the last reset: counts8[0..5] by tile (as af_last_gemm_plan), [6] LDS-halo 3x3 kernel,
- * [7] launches that sliced K (also counted under their tile).  Lets a whole-model test assert which kernels it ran. */
-int af_gemm_plan_counts(int64_t* counts8);
+/* launches per tiling since the last reset: counts10[0..5] by tile (as af_last_gemm_plan), [6] LDS-halo 3x3 kernel,
+ * [7] launches that sliced K (also counted under their tile), [8] / [9] ping-pong launches whose epilogue applied a
+ * folded LayerNorm / produced LayerNorm row statistics.  Lets a whole-model test assert which kernels it ran. */
+int af_gemm_plan_counts(int64_t* counts10);
 int af_gemm_plan_counts_reset(void);
 
 /* ---- tuning / diagnostic knobs ----
@@ -159,7 +160,7 @@ int af_gemm_plan_counts_reset(void);
  * launch path reads the environment.  The parity tests use af_knob_set to reach a kernel variant regardless of the
  * planner's choice and af_knob_reset to restore the load-time values.  No knob changes results beyond the summation
  * order of the chosen tiling.  Names: splitk_target, conv_halo, gemm_pp, gemm_pp_geglu_minkt, gemm_pp_minfill,
- * gemm_tile, gemm_splitk, gemm_groupm, gemm_dma, pp_direct, attn_w4, attn_ring, gn_small, gn_fold. */
+ * gemm_tile, gemm_splitk, gemm_groupm, gemm_dma, pp_direct, attn_w4, attn_ring, gn_small, gn_fold, ln_fuse. */
 int af_knob_set(const char* name, int value);
 int af_knob_get(const char* name, int* value);
 int af_knob_reset(void);

@@ -25,19 +25,24 @@ dev = torch.device("cuda:0")
 Bf = args.bf
 
 
+GEMM_CLASSES = (0, 5, 6, 7)   # four-wave / halo kernels + the three ping-pong instantiations (include/adaface_hip.h)
+
+
 def timed(cls, fn):
     fn()  # warm
     torch.cuda.synchronize()
+    classes = GEMM_CLASSES if cls == 0 else (cls,)
     lib.af_prof_reset()
-    lib.af_prof_enable(1 << cls)
+    lib.af_prof_enable(sum(1 << c for c in classes))
     for _ in range(args.reps):
         fn()
     torch.cuda.synchronize()
     lib.af_prof_enable(0)
-    n = 5
+    n = 8
     ms = (C.c_double * n)(); la = (C.c_int64 * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)()
     lib.af_prof_collect(n, ms, la, fl, by)
-    return ms[cls] / la[cls], fl[cls] / la[cls], by[cls] / la[cls]
+    tms, tla = sum(ms[c] for c in classes), sum(la[c] for c in classes)
+    return tms / tla, sum(fl[c] for c in classes) / tla, sum(by[c] for c in classes) / tla
 
 
 def show(name, ms, flops, byts):

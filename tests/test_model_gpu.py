@@ -256,6 +256,35 @@ def test_sd15_vae_encoder_golden(gpu, report, dtype):
 BATCH_TOL = {"f32": 1e-5, "bf16": 3e-2}
 
 
+def test_sd15_unet_layernorm_folding_ab(gpu, report, knobs):
+    """bf16 at the benchmark batch: the LayerNorm-folded transformer GEMMs (mu / rstd applied in the consumer's epilogue on
+    W * gamma, row statistics from the producer's epilogue) against the same forward with stand-alone LayerNorm kernels.
+    Both are bf16 forwards that round differently, so they are held to the bf16 bar against each other."""
+    from adaface_amd import _lib
+    from adaface_amd.engine import Engine
+    from adaface_amd.synth import synth_weights_into
+    cfg = O.SD15_UNET
+    g = torch.Generator().manual_seed(35)
+    x = torch.randn(16, 4, 64, 64, generator=g).to(gpu)
+    t = torch.full((16,), 301, dtype=torch.long, device=gpu)
+    ctx = torch.randn(16 * 16, 77, cfg.context_dim, generator=g).to(gpu)
+    eng = Engine(dtype="bf16", unet=_unet_kwargs(cfg))
+    synth_weights_into(eng, O.unet_param_shapes(cfg), seed=36, device=gpu)
+    eng.set_context(ctx, 16, layerwise=True)
+    _lib.plan_counts(reset=True)
+    eps_fused = eng.unet_forward(x, t)
+    pc = _lib.plan_counts(reset=True)
+    knobs("ln_fuse", 0)
+    eps_plain = eng.unet_forward(x, t)
+    pc0 = _lib.plan_counts(reset=True)
+    assert pc["ln_consumer"] == 30 and pc0["ln_consumer"] == 0 and pc0["ln_producer"] == 0, (pc, pc0)
+    scale = eps_plain.abs().max().item()
+    err = (eps_fused - eps_plain).abs().max().item() / scale
+    report("sd15_unet Bf=16 LayerNorm-folded vs stand-alone LayerNorm [bf16]", err, scale, BATCH_TOL["bf16"])
+    assert torch.isfinite(eps_fused).all() and err <= BATCH_TOL["bf16"], err
+    eng.close()
+
+
 def test_sd15_unet_batch_consistency(gpu, report):
     """f32 mode: Bf = 16 vs Bf = 2 pairs agree to 1e-5 (summation order only).  bf16 mode: two tilings round their
     activations differently, so a Bf = 16 and a Bf = 2 forward differ by about sqrt(2) x the bf16 forward error itself
@@ -280,8 +309,10 @@ def test_sd15_unet_batch_consistency(gpu, report):
         eng.set_context(ctx, 2 * B, layerwise=True)
         eps16 = eng.unet_forward(x, t)
         pc = _lib.plan_counts(reset=True)
-        if dtype == "bf16":      # the launches the benchmark times: eight-wave ping-pong tiles and a sliced-K launch
+        if dtype == "bf16":      # the launches the benchmark times: eight-wave ping-pong tiles and a sliced-K launch,
+            # and the LayerNorm-folded GEMMs of the 64x64 and 32x32 transformers (3 consumers + 3 producers each)
             assert pc["tile4"] > 0 and pc["tile5"] > 0 and pc["splitk"] > 0, pc
+            assert pc["ln_consumer"] == 30 and pc["ln_producer"] == 30, pc
             e = (eps16 - eps_f32).abs().max().item() / eps_f32.abs().max().item()
             report("sd15_unet Bf=16 bf16 forward vs f32-mode forward of the same batch", e, eps_f32.abs().max().item(), BATCH_TOL["bf16"])
             assert e <= BATCH_TOL["bf16"], e
