@@ -227,14 +227,14 @@ struct ConvGemmParams {
   //   producer side: ln_stats_out != null -> besides its output the GEMM writes, per output row m and per 80-column slab
   //     part = 2 * (n tile) + wave group, the sum and the sum of squares of the bf16-ROUNDED values it stored:
   //     ln_stats_out[(part * M + m) * 2 + {0, 1}]  (fp32; fixed summation order, no atomics: deterministic)
+  //     (ln_finalize_kernel turns them into ln_stats[m] = (mu, rstd): one tiny launch instead of every column tile's
+  //     workgroup re-reducing the slabs in front of its pipeline — that cost 20-60 us per consumer launch)
   //   consumer side: ln_stats != null -> the A operand is the un-normalised x and W holds W * gamma; the epilogue applies
-  //     out = rstd[m] * (acc - mu[m] * ln_colsum[n]) + bias[n] with mu / rstd from the ln_parts partial sums of row m
-  //     (ln_count = normalised width C) and bias = W beta + b precomputed at load time.  GEGLU composes with it.
+  //     out = rstd[m] * (acc - mu[m] * ln_colsum[n]) + bias[n], bias = W beta + b precomputed at load time.  GEGLU
+  //     composes with it.
   float* ln_stats_out;
   const float* ln_stats;
   const float* ln_colsum;
-  int ln_parts;
-  float ln_inv_count, ln_eps;
   int pp_epilogue;        // ping-pong kernel (set by the launcher): 0 = direct for GEGLU / split-K slabs and LDS
                           // otherwise, 1 = always through LDS, 2 = always direct
 };

@@ -650,20 +650,12 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
 #pragma unroll
     for (int i = 0; i < NI; ++i) ln_cs[i] = *reinterpret_cast<const float4*>(p.ln_colsum + n0 + g * C::HN + i * 16 + cl);
 #pragma unroll
-    for (int j = 0; j < MI; ++j) {
+    for (int j = 0; j < MI; ++j) {   // (mu, rstd) per row, finalised by ln_finalize_kernel; consumed in the epilogue only
       const int m = m0 + wq * 64 + j * 16 + (lane & 15);
-      float s1 = 0.f, s2 = 0.f;
-      if (m < p.M) {
-        for (int part = 0; part < p.ln_parts; ++part) {   // fixed order: deterministic
-          const float2 st = *reinterpret_cast<const float2*>(p.ln_stats + ((long)part * p.M + m) * 2);
-          s1 += st.x;
-          s2 += st.y;
-        }
-      }
-      const float mu = s1 * p.ln_inv_count;
-      const float var = fmaxf(s2 * p.ln_inv_count - mu * mu, 0.f);
-      ln_mu[j] = mu;
-      ln_rs[j] = __builtin_amdgcn_rsqf(var + p.ln_eps);
+      float2 st = float2{0.f, 0.f};
+      if (m < p.M) st = *reinterpret_cast<const float2*>(p.ln_stats + (long)m * 2);
+      ln_mu[j] = st.x;
+      ln_rs[j] = st.y;
     }
   }
 
@@ -1175,6 +1167,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvGemmParams
     for (int e = 0; e < 4; ++e) o.e[e] = from_f32<T>(v[e]);
     o.store(out + (long)m * p.ldo + n);
   }
+}
+
+// LayerNorm row statistics: partial sums [parts][M][2] (sum, sum of squares; written by the LNMODE 2 epilogue) ->
+// [M][2] = (mu, rstd), summed in slab order (deterministic).  One thread per row.
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, int parts, int M, float inv_count,
+                                                          float eps, float* __restrict__ out) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int q = 0; q < parts; ++q) {
+    const float2 st = *reinterpret_cast<const float2*>(part + ((long)q * M + m) * 2);
+    s1 += st.x;
+    s2 += st.y;
+  }
+  const float mu = s1 * inv_count;
+  const float var = fmaxf(s2 * inv_count - mu * mu, 0.f);
+  *reinterpret_cast<float2*>(out + (long)m * 2) = float2{mu, __builtin_amdgcn_rsqf(var + eps)};
+}
+int af_launch_ln_finalize(const float* part, int parts, int M, int count, float eps, float* out, hipStream_t s) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, part, parts, M, 1.0f / (float)count, eps, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
 }
 
 // ---------------------------------------------------------------------------

@@ -60,6 +60,9 @@ template <typename T>
 int af_launch_ln_fold(const void* W, void* Wf, const float* gamma, const float* beta, const float* bias, float* colsum,
                       float* biasf, int rows, int K, int ldw, hipStream_t s);
 
+// LayerNorm row statistics [parts][M][2] (sum, sum of squares) -> [M][2] (mu, rstd)
+int af_launch_ln_finalize(const float* part, int parts, int M, int count, float eps, float* out, hipStream_t s);
+
 // plan of the most recent af_launch_conv_gemm (diagnostics, af_last_gemm_plan)
 extern AfGemmPlan g_af_last_plan;
 extern long g_af_plan_counts[10];

@@ -691,9 +691,13 @@ struct Runner {
   // bounds check returns for iy == Hi / ix == Wi
   // LayerNorm folded into a ping-pong GEMM (ConvGemmParams::ln_*): consumer (stats + colsum) or producer (stats_out)
   struct LnArgs {
-    const float* stats = nullptr; int parts = 0; const float* colsum = nullptr; float eps = 1e-5f; int count = 0;
-    float* stats_out = nullptr;
+    const float* stats = nullptr; const float* colsum = nullptr;   // consumer: finalised (mu, rstd) per row, column sums
+    float* stats_out = nullptr;                                    // producer: partial sums [parts][M][2]
   };
+  int ln_finalize(const float* part, int parts, long M, int count, float eps, float* out) {
+    if (dry) return 0;
+    return af_launch_ln_finalize(part, parts, (int)M, count, eps, out, s);
+  }
   void conv_params(ConvGemmParams& p, const Linear& L, const Act& x, const Act& out, int stride, int up,
                    const Act* residual, const void* rowbias, int ldrb, int n_valid, int pad) const {
     memset(&p, 0, sizeof(p));
@@ -735,8 +739,7 @@ struct Runner {
     ConvGemmParams p;
     conv_params(p, L, x, out, stride, up, residual, rowbias, ldrb, n_valid, pad);
     if (ln) {
-      p.ln_stats = ln->stats; p.ln_parts = ln->parts; p.ln_colsum = ln->colsum; p.ln_eps = ln->eps;
-      p.ln_inv_count = ln->count > 0 ? 1.0f / (float)ln->count : 0.f;
+      p.ln_stats = ln->stats; p.ln_colsum = ln->colsum;
       p.ln_stats_out = ln->stats_out;
     }
     if (x.C < L.cin || x.ld < L.cin_pad) {
@@ -846,14 +849,18 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out) {
     if (ok) ln_parts = pp;
   }
   const size_t st_elems = (size_t)ln_parts * B * N * 2;
-  float* st_t = ln_parts ? reinterpret_cast<float*>(R.A.alloc(st_elems * sizeof(float))) : nullptr;    // stats of t
-  float* st_1 = ln_parts ? reinterpret_cast<float*>(R.A.alloc(st_elems * sizeof(float))) : nullptr;    // ... of t1
-  float* st_2 = ln_parts ? reinterpret_cast<float*>(R.A.alloc(st_elems * sizeof(float))) : nullptr;    // ... of t2
-  if (ln_parts && !st_2) { af_set_error_msg("arena exhausted (LayerNorm statistics)"); return AF_ERR_STATE; }
+  float* st_part = ln_parts ? reinterpret_cast<float*>(R.A.alloc(st_elems * sizeof(float))) : nullptr;       // partial sums
+  float* st_row = ln_parts ? reinterpret_cast<float*>(R.A.alloc((size_t)B * N * 2 * sizeof(float))) : nullptr;  // (mu, rstd)
+  if (ln_parts && !st_row) { af_set_error_msg("arena exhausted (LayerNorm statistics)"); return AF_ERR_STATE; }
+  float *st_t = st_part, *st_1 = st_part, *st_2 = st_part;   // one tensor's statistics are live at a time
   auto producer = [&](float* st) { Runner::LnArgs a; a.stats_out = st; return a; };
   auto consumer = [&](const float* st, const float* cs, const Norm& ln) {
-    Runner::LnArgs a; a.stats = st; a.parts = ln_parts; a.colsum = cs; a.eps = ln.eps; a.count = C; return a;
+    Runner::LnArgs a; a.colsum = cs;
+    a.stats = st_row;
+    (void)st; (void)ln;
+    return a;
   };
+  auto finalize = [&](const float* st, const Norm& ln) { return R.ln_finalize(st, ln_parts, (long)B * N, C, ln.eps, st_row); };
   {
     const Runner::LnArgs pa = producer(st_t);
     AF_TRY(R.conv(w.proj_in, g, t, 1, 0, nullptr, nullptr, 0, -1, -1, ln_parts ? &pa : nullptr));
@@ -865,6 +872,7 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out) {
     Act n = R.alloc_act(B, H, W, C);
     Act qkv = R.alloc_act(B, H, W, 3 * C);
     if (ln_parts) {
+      AF_TRY(finalize(st_t, blk.ln1));
       const Runner::LnArgs ca = consumer(st_t, blk.qkv1_cs, blk.ln1);
       AF_TRY(R.conv(blk.qkv1_ln, t, qkv, 1, 0, nullptr, nullptr, 0, -1, -1, &ca));
     } else {
@@ -882,6 +890,7 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out) {
     // --- x = x + attn2(norm2(x), context) ---
     Act q = R.alloc_act(B, H, W, C);
     if (ln_parts) {
+      AF_TRY(finalize(st_1, blk.ln2));
       const Runner::LnArgs ca = consumer(st_1, blk.q2_cs, blk.ln2);
       AF_TRY(R.conv(blk.q2_ln, t1, q, 1, 0, nullptr, nullptr, 0, -1, -1, &ca));
     } else {
@@ -942,6 +951,7 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out) {
     // --- x = ff(norm3(x)) + x ---
     Act f = R.alloc_act(B, H, W, 4 * C);
     if (ln_parts) {
+      AF_TRY(finalize(st_2, blk.ln3));
       const Runner::LnArgs ca = consumer(st_2, blk.ff1_cs, blk.ln3);
       AF_TRY(R.conv(blk.ff1_ln, t2, f, 1, 0, nullptr, nullptr, 0, 8 * C, -1, &ca));
     } else {
