@@ -80,6 +80,7 @@ struct AfKnobs {
   int attn_ring;            // AF_ATTN_RING            0 = dh-40 bf16 attention on the four-wave kernel instead of the ring kernel
   int gn_small;             // AF_GN_SMALL             0 = no single-launch GroupNorm for small maps
   int gn_fold;              // AF_GN_FOLD              0 = separate GroupNorm finalize pass
+  int conv_tap_inner;       // AF_CONV_TAP_INNER       0 = ping-pong convs walk K tap-outermost (the round-1 order)
   int ln_fuse;              // AF_LN_FUSE              0 = stand-alone LayerNorm kernels in front of the transformer GEMMs
 };
 extern AfKnobs g_af_knobs;
@@ -235,6 +236,7 @@ struct ConvGemmParams {
   float* ln_stats_out;
   const float* ln_stats;
   const float* ln_colsum;
+  int k_tap_inner;        // ping-pong kernel (set by the launcher): K walked as (channel chunk, tap) instead of (tap, chunk)
   int pp_epilogue;        // ping-pong kernel (set by the launcher): 0 = direct for GEGLU / split-K slabs and LDS
                           // otherwise, 1 = always through LDS, 2 = always direct
 };

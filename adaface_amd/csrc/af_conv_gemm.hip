@@ -558,8 +558,18 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     const int n = n0 + (wq + 4 * q) * 8 + srow;
     w_off[q] = n < p.Wrows ? (unsigned)((long)n * p.ldw * 2) + lchunk : 0xFFFFFFFFu;
   }
+  // K order.  The sum over (tap, channel chunk) can be walked either way; with the TAP innermost (k_tap_inner) the nine
+  // taps of a channel chunk re-read the same few input rows back to back, so eight of nine gathers hit the XCD's L2
+  // instead of each tap streaming the whole input slice again (PMC: 225 MB fetched per launch against ~50 MB of input
+  // with the tap outermost).  The weight tile of (tap, chunk) is the 128-byte run at column tap * Cin + c0 either way.
   int ky, kx, c0, ktile = kt_begin;   // filter tap / channel offset / K tile of the NEXT tile this wave stages
-  {
+  if (p.k_tap_inner) {
+    const int taps = p.ks * p.ks;
+    const int cc = kt_begin / taps, tap = kt_begin - cc * taps;
+    c0 = cc * 64;
+    ky = tap / p.ks;
+    kx = tap - ky * p.ks;
+  } else {
     const int k0 = kt_begin * 64;
     const int tap = k0 / p.Cin;
     c0 = k0 - tap * p.Cin;
@@ -578,7 +588,8 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     }
   };
   auto stage = [&](int slot_off) {
-    const unsigned c0b = (unsigned)c0 * 2u, k0b = (unsigned)ktile * 128u;
+    const unsigned c0b = (unsigned)c0 * 2u;
+    const unsigned k0b = p.k_tap_inner ? (unsigned)((ky * p.ks + kx) * p.Cin + c0) * 2u : (unsigned)ktile * 128u;
     char* base = smem + slot_off;
     pp_static_for<0, NPMAX>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
@@ -590,10 +601,17 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
       }
     });
     ++ktile;
-    c0 += 64;
-    if (c0 >= p.Cin) {
-      c0 = 0;
-      if (++kx >= p.ks) { kx = 0; ++ky; }
+    if (p.k_tap_inner) {
+      if (++kx >= p.ks) {
+        kx = 0;
+        if (++ky >= p.ks) { ky = 0; c0 += 64; }
+      }
+    } else {
+      c0 += 64;
+      if (c0 >= p.Cin) {
+        c0 = 0;
+        if (++kx >= p.ks) { kx = 0; ++ky; }
+      }
     }
   };
   auto wait_keep1 = [&]() { if (g == 0) pp_wait_vm<NP0>(); else pp_wait_vm<NP1>(); };
@@ -1298,7 +1316,10 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
     const int tbn = pl.halo_tw ? ((pl.tile == 0 || pl.tile == 1) ? 128 : 64) : (pl.tile == 5 ? 160 : pl.tile == 4 ? 128 : bn[pl.tile]);
     const int MT = (p.M + tbm - 1) / tbm, NT = (p.N + tbn - 1) / tbn;
     const int resident = pl.tile >= 4 ? 32 : 32 * ((tbm * tbn >= 128 * 128) ? 2 : 3);
-    const double xb = (double)p.M * (p.K / (p.ks * p.ks)) * (pl.halo_tw ? 1.5 : (double)(p.ks * p.ks) / (p.stride * p.stride));
+    // activation bytes a column of tiles streams per unit of M: every tap re-reads the input unless the taps of a channel
+    // chunk follow each other (LDS halo kernel; ping-pong kernel with the tap innermost: ~1.5x halo rows at stride 1)
+    const bool taps_reuse = pl.halo_tw || (pl.tile >= 4 && p.ks > 1 && g_af_knobs.conv_tap_inner);
+    const double xb = (double)p.M * (p.K / (p.ks * p.ks)) * (taps_reuse ? (p.stride == 1 ? 1.5 : 1.0) : (double)(p.ks * p.ks) / (p.stride * p.stride));
     const double wb = (double)p.N * p.K;
     double bestc = 1e300;
     int bestg = 1;
@@ -1415,6 +1436,7 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   }
   p.group_m = pl.group_m > 0 ? pl.group_m : 1;
   p.pp_epilogue = g_af_knobs.pp_direct < 0 ? 0 : (g_af_knobs.pp_direct ? 2 : 1);
+  p.k_tap_inner = (p.ks > 1 && g_af_knobs.conv_tap_inner) ? 1 : 0;
   const int prof_cls = pl.tile == 5 ? ((p.ks == 1 && p.pad == 0) ? AF_K_PP160_PLAIN : AF_K_PP160_GATHER)
                                      : (pl.tile == 4 ? AF_K_PP128 : AF_K_CONV_GEMM);
   AfProfScope prof(prof_cls, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K) * batch,

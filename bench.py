@@ -47,7 +47,7 @@ K_NAMES = ["conv_gemm_other", "attention", "groupnorm", "layernorm", "other", "c
            "conv_gemm_pp<160,plain>", "conv_gemm_pp<128>"]
 GEMM_CLASSES = (0, 5, 6, 7)
 DOMINANT = 5            # conv_gemm_pp_kernel<160, true>: the 3x3 convolutions, the largest single kernel of a step
-DOMINANT_KERNEL = "conv_gemm_pp_kernel<160, true>"
+DOMINANT_KERNEL = "conv_gemm_pp_kernel<160, true, 0>"
 
 
 def parse():

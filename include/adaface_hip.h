@@ -160,7 +160,7 @@ int af_gemm_plan_counts_reset(void);
  * launch path reads the environment.  The parity tests use af_knob_set to reach a kernel variant regardless of the
  * planner's choice and af_knob_reset to restore the load-time values.  No knob changes results beyond the summation
  * order of the chosen tiling.  Names: splitk_target, conv_halo, gemm_pp, gemm_pp_geglu_minkt, gemm_pp_minfill,
- * gemm_tile, gemm_splitk, gemm_groupm, gemm_dma, pp_direct, attn_w4, attn_ring, gn_small, gn_fold, ln_fuse. */
+ * gemm_tile, gemm_splitk, gemm_groupm, gemm_dma, pp_direct, attn_w4, attn_ring, gn_small, gn_fold, conv_tap_inner, ln_fuse. */
 int af_knob_set(const char* name, int value);
 int af_knob_get(const char* name, int* value);
 int af_knob_reset(void);
