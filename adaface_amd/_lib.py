@@ -33,6 +33,9 @@ class AfConfig(C.Structure):
         ("vae_z_channels", C.c_int), ("vae_embed_dim", C.c_int),
         ("n_vae_ch_mult", C.c_int), ("vae_ch_mult", C.c_int * 8),
         ("build_vae_encoder", C.c_int), ("vae_in_channels", C.c_int),
+        ("build_clip", C.c_int),
+        ("clip_vocab", C.c_int), ("clip_hidden", C.c_int), ("clip_layers", C.c_int), ("clip_heads", C.c_int),
+        ("clip_intermediate", C.c_int), ("clip_max_pos", C.c_int),
     ]
 
 
@@ -84,7 +87,9 @@ _SIGS = [
     ("af_op_linear", C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     ("af_op_groupnorm", C.c_int, [C.c_int, _P, _P, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("af_op_layernorm", C.c_int, [C.c_int, _P, _P, _P, C.c_float, _P, C.c_int64, C.c_int, _P]),
-    ("af_op_attention", C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
+    ("af_op_attention", C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
+    ("af_clip_embed_tokens", C.c_int, [_P, _P, C.c_int64, _P, _P]),
+    ("af_clip_text_forward", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P]),
     ("af_op_timestep_embedding", C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGS]

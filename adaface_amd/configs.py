@@ -41,4 +41,7 @@ def tiny_config() -> dict:
     p = cfg["model"]["params"]
     p["unet_config"]["params"].update(model_channels=64, num_heads=2, context_dim=64)
     p["first_stage_config"]["params"]["ddconfig"].update(ch=64, ch_mult=[1, 2, 2, 2])
+    # a text tower of the same structure as CLIP ViT-L/14's, 12x narrower, whose width is the tiny U-Net's context_dim
+    p["cond_stage_config"]["params"] = {"clip_config": dict(vocab=1000, hidden=64, layers=3, heads=4, intermediate=128,
+                                                            max_pos=77)}
     return cfg

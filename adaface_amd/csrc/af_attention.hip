@@ -213,6 +213,13 @@ template <typename T, int DH> __device__ __forceinline__ void attn_body(const At
         for (int r = 0; r < 16; ++r)
           if (t0 + 32 * kb + acc_row(r, h) >= p.Nk) s[kb][r] = -INFINITY;
     }
+    if (p.causal && t0 + 63 > q0) {  // causal mask: keys after the query (tiles wholly before this wave's queries skip it)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t0 + 32 * kb + acc_row(r, h) > q) s[kb][r] = -INFINITY;
+    }
     // ---- online softmax (per lane = per query; the two lane halves hold disjoint keys) ----
     // tile maximum: four independent max3 chains, then across the two lane halves.  The chain heads read MFMA
     // results from inline asm: hipcc inserts no MFMA-result wait states for an asm statement (cdna guide 5.7 item 2),
@@ -662,7 +669,7 @@ template <typename T, int DH> static int launch_attn(const AttnParams& p, int B,
   if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&attn_kernel<T, DH>), C::LDS_BYTES)) return rc;
   if (int rc = af_ensure_dynamic_lds(attr_done_w4, reinterpret_cast<const void*>(&attn_kernel_w4<T, DH>), C::LDS_BYTES)) return rc;
   if constexpr (C::BF && DH == 40) {
-    if (g_af_knobs.attn_ring) {   // eight-wave LDS-DMA ring kernel (the 64x64 level)
+    if (g_af_knobs.attn_ring && !p.causal) {   // eight-wave LDS-DMA ring kernel (the 64x64 level)
       static unsigned long long attr_done_ring = 0;
       if (int rc = af_ensure_dynamic_lds(attr_done_ring, reinterpret_cast<const void*>(&ring40::attn_ring40_kernel), ring40::LDS_BYTES)) return rc;
       hipLaunchKernelGGL(ring40::attn_ring40_kernel, dim3((p.Nq + 255) / 256, p.H, B), dim3(ring40::NT), ring40::LDS_BYTES, stream, p);

@@ -256,4 +256,5 @@ struct AttnParams {
   int Nq, Nk, H;
   float scale;
   float* lse;   // optional [B][H][Nq]: log2-domain log-sum-exp of the scaled scores (m + log2 l); null = off
+  int causal;   // != 0: query i attends to keys <= i only (the CLIP text tower's mask, modeling_clip causal mask)
 };

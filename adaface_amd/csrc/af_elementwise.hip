@@ -180,6 +180,46 @@ __global__ void silu_kernel(const T* __restrict__ x, T* __restrict__ y, long n) 
   }
 }
 
+// y = x * sigmoid(1.702 x) ("quick_gelu", the CLIP text tower's activation: transformers CLIPMLP, hidden_act of
+// openai/clip-vit-large-patch14) elementwise (T)
+template <typename T>
+__global__ void quick_gelu_kernel(const T* __restrict__ x, T* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float f = to_f32<T>(x[i]);
+    y[i] = from_f32<T>(f / (1.0f + expf(-1.702f * f)));
+  }
+}
+// CLIPTextEmbeddings (as patched by encoders/modules.py:198-227): rows of the token table -> fp32 [n, D] (the
+// EmbeddingManager patches these on the caller's side), then  x = T(inputs_embeds + position_embedding[pos])
+template <typename T>
+__global__ void embed_rows_kernel(const long long* __restrict__ ids, const T* __restrict__ table, int vocab, int D,
+                                  float* __restrict__ y, long n) {
+  const long total = n * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D;
+    const int c = (int)(i - r * D);
+    long long id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    y[i] = to_f32<T>(table[id * D + c]);
+  }
+}
+template <typename T>
+__global__ void add_pos_cast_kernel(const float* __restrict__ x, const T* __restrict__ pos, int Tn, int D,
+                                    T* __restrict__ y, long rows) {
+  const long total = rows * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D;
+    const int c = (int)(i - r * D);
+    y[i] = from_f32<T>(x[i] + to_f32<T>(pos[(r % Tn) * D + c]));
+  }
+}
+// y (fp32) = w0 * a + w1 * b   (last-layers blend of the CLIP hidden states, encoders/modules.py:361-368), T inputs
+template <typename T>
+__global__ void blend2_kernel(const T* __restrict__ a, float w0, const T* __restrict__ b, float w1, T* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = from_f32<T>(w0 * to_f32<T>(a[i]) + w1 * to_f32<T>(b[i]));
+}
+
 // dst[pix][off + c] = src[pix][c]   (channel concat; 16-byte vectors)
 template <typename T>
 __global__ void copy_channels_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd, int off,
@@ -390,6 +430,33 @@ template <typename T> int af_launch_silu(const void* x, void* y, long n, hipStre
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+template <typename T> int af_launch_quick_gelu(const void* x, void* y, long n, hipStream_t s) {
+  hipLaunchKernelGGL((quick_gelu_kernel<T>), EW_GRID(n), dim3(256), 0, s, reinterpret_cast<const T*>(x),
+                     reinterpret_cast<T*>(y), n);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <typename T>
+int af_launch_embed_rows(const long long* ids, const void* table, int vocab, int D, float* y, long n, hipStream_t s) {
+  hipLaunchKernelGGL((embed_rows_kernel<T>), EW_GRID(n * D), dim3(256), 0, s, ids, reinterpret_cast<const T*>(table), vocab,
+                     D, y, n);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <typename T>
+int af_launch_add_pos_cast(const float* x, const void* pos, int Tn, int D, void* y, long rows, hipStream_t s) {
+  hipLaunchKernelGGL((add_pos_cast_kernel<T>), EW_GRID(rows * D), dim3(256), 0, s, x, reinterpret_cast<const T*>(pos), Tn, D,
+                     reinterpret_cast<T*>(y), rows);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <typename T>
+int af_launch_blend2(const void* a, float w0, const void* b, float w1, void* y, long n, hipStream_t s) {
+  hipLaunchKernelGGL((blend2_kernel<T>), EW_GRID(n), dim3(256), 0, s, reinterpret_cast<const T*>(a), w0,
+                     reinterpret_cast<const T*>(b), w1, reinterpret_cast<T*>(y), n);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
 template <typename T>
 int af_launch_copy_channels(const void* src, int lds_, void* dst, int ldd, int off, int Cn, long npix, hipStream_t s) {
   constexpr int EPC = 16 / sizeof(T);
@@ -460,6 +527,10 @@ int af_launch_nchw_to_uint8(const float* x, uint8_t* y, int B, int HW, hipStream
   template int af_launch_cast_to_f32<T>(const void*, float*, long, hipStream_t);                              \
   template int af_launch_timestep_embedding<T>(const long long*, void*, int, int, hipStream_t);               \
   template int af_launch_silu<T>(const void*, void*, long, hipStream_t);                                      \
+  template int af_launch_quick_gelu<T>(const void*, void*, long, hipStream_t);                                \
+  template int af_launch_embed_rows<T>(const long long*, const void*, int, int, float*, long, hipStream_t);   \
+  template int af_launch_add_pos_cast<T>(const float*, const void*, int, int, void*, long, hipStream_t);      \
+  template int af_launch_blend2<T>(const void*, float, const void*, float, void*, long, hipStream_t);         \
   template int af_launch_copy_channels<T>(const void*, int, void*, int, int, int, long, hipStream_t);         \
   template int af_launch_softmax_rows<T>(void*, int, int, long, hipStream_t);                                 \
   template int af_launch_transpose<T>(const void*, long, int, void*, long, int, int, int, hipStream_t);       \

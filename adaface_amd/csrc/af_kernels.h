@@ -34,6 +34,13 @@ int af_launch_conv_attn(const void* q, int ldq, long bsq, const void* kv, int ld
 template <typename T> int af_launch_cast_to_f32(const void* x, float* y, long n, hipStream_t s);
 template <typename T> int af_launch_timestep_embedding(const long long* t, void* y, int B, int dim, hipStream_t s);
 template <typename T> int af_launch_silu(const void* x, void* y, long n, hipStream_t s);
+// CLIP text tower pieces (encoders/modules.py:179-463; transformers CLIPTextModel)
+template <typename T> int af_launch_quick_gelu(const void* x, void* y, long n, hipStream_t s);
+template <typename T>
+int af_launch_embed_rows(const long long* ids, const void* table, int vocab, int D, float* y, long n, hipStream_t s);
+template <typename T>
+int af_launch_add_pos_cast(const float* x, const void* pos, int Tn, int D, void* y, long rows, hipStream_t s);
+template <typename T> int af_launch_blend2(const void* a, float w0, const void* b, float w1, void* y, long n, hipStream_t s);
 template <typename T>
 int af_launch_copy_channels(const void* src, int lds_, void* dst, int ldd, int off, int Cn, long npix, hipStream_t s);
 int af_launch_ddim_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, long n,

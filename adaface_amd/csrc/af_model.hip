@@ -183,6 +183,10 @@ struct VaeAttnW {
   Linear qkv, proj_out;
   int C = 0;
 };
+struct ClipLayerW {   // CLIPEncoderLayer (transformers modeling_clip): pre-LN attention + pre-LN MLP
+  Norm ln1, ln2;
+  Linear qkv, out, fc1, fc2;
+};
 enum LayerKind { L_CONV_IN, L_RES, L_XFMR, L_DOWN, L_UP };
 struct LayerRef {
   LayerKind kind;
@@ -193,7 +197,7 @@ struct UBlock {
 };
 
 struct Slot {  // one expected state_dict tensor
-  enum Kind { WEIGHT, BIAS_VEC } kind = WEIGHT;
+  enum Kind { WEIGHT, BIAS_VEC, TABLE } kind = WEIGHT;   // TABLE: [rows][cin] matrix stored as is in the storage dtype
   std::vector<int64_t> shape;
   // WEIGHT: destination rows in a (possibly fused) repacked buffer
   void* dst = nullptr;
@@ -245,6 +249,12 @@ struct af_handle {
   std::vector<Linear> edown;
   int emid1 = -1, emid2 = -1;
   std::vector<VLevel> elevels;
+
+  // CLIP text tower
+  void* clip_tok = nullptr;     // token embedding table [vocab][hidden], storage dtype
+  void* clip_pos = nullptr;     // position embedding table [max_pos][hidden]
+  std::vector<ClipLayerW> clip_layers;
+  Norm clip_final_ln;
 
   // subject-token conv attention (af_set_conv_attn): kernel size (3, or <= 0 = off), the samples that carry the
   // subject and the text positions of its ks*ks tokens (tap order)
@@ -615,6 +625,49 @@ static int build_vae(Builder& b) {
   return b.rc;
 }
 
+// mirrors CLIPTextModel (transformers modeling_clip.py: CLIPTextEmbeddings, CLIPEncoderLayer x L, final_layer_norm) under
+// the checkpoint prefix the reference uses for it (ddpm.py: cond_stage_model = FrozenCLIPEmbedder, .transformer)
+static int build_clip(Builder& b) {
+  af_handle* h = b.h;
+  const af_config& c = h->cfg;
+  const std::string P = "cond_stage_model.transformer.text_model.";
+  const int D = c.clip_hidden, F = c.clip_intermediate;
+  if (D % bk_of(h->dtype) != 0 || F % bk_of(h->dtype) != 0 || c.clip_heads <= 0 || D % c.clip_heads != 0) {
+    af_set_error_msg("clip: hidden (%d) / intermediate (%d) must be multiples of %d", D, F, bk_of(h->dtype));
+    return AF_ERR_INVALID;
+  }
+  auto table = [&](const std::string& name, void*& dst, int rows) {
+    dst = b.dmalloc((size_t)rows * D * esize(h->dtype));
+    Slot s;
+    s.kind = Slot::TABLE;
+    s.shape = {rows, D};
+    s.dst = dst;
+    s.rows = rows; s.cin = D; s.cin_pad = D; s.ks = 1; s.ldw = D;
+    b.add_slot(name, s);
+  };
+  table(P + "embeddings.token_embedding.weight", h->clip_tok, c.clip_vocab);
+  table(P + "embeddings.position_embedding.weight", h->clip_pos, c.clip_max_pos);
+  h->clip_layers.resize(c.clip_layers);
+  for (int i = 0; i < c.clip_layers; ++i) {
+    ClipLayerW& L = h->clip_layers[i];
+    const std::string p = P + "encoder.layers." + std::to_string(i);
+    b.make_norm(L.ln1, p + ".layer_norm1", D, 1e-5f);
+    b.make_norm(L.ln2, p + ".layer_norm2", D, 1e-5f);
+    b.alloc_linear(L.qkv, D, 3 * D, 1, false);
+    L.qkv.bias = b.alloc_vec(3 * D);
+    const char* nm[3] = {".self_attn.q_proj", ".self_attn.k_proj", ".self_attn.v_proj"};
+    for (int j = 0; j < 3; ++j) {
+      b.weight_slot(p + nm[j] + ".weight", L.qkv, D, j * D, 0, false);
+      b.vec_slot(p + nm[j] + ".bias", L.qkv.bias + j * D, D);
+    }
+    b.make_conv(L.out, p + ".self_attn.out_proj", D, D, 1, true, false);
+    b.make_conv(L.fc1, p + ".mlp.fc1", D, F, 1, true, false);
+    b.make_conv(L.fc2, p + ".mlp.fc2", F, D, 1, true, false);
+  }
+  b.make_norm(h->clip_final_ln, P + "final_layer_norm", D, 1e-5f);
+  return b.rc;
+}
+
 static void make_vae_attn(Builder& b, VaeAttnW& a, const std::string& p, int C) {
   a.C = C;
   b.make_norm(a.gn, p + ".norm", C, 1e-6f);
@@ -783,7 +836,7 @@ struct Runner {
   }
   // samples [b0, b0 + nb) of the batch (nb < 0: all of o.B); lse: optional [nb][heads][Nq] log-sum-exp output
   int attention(const void* q, int ldq, long bsq, const void* k, int ldk, long bsk, const void* v, int ldv, long bsv,
-                Act& o, int Nq, int Nk, int heads, int dh, int b0 = 0, int nb = -1, float* lse = nullptr) {
+                Act& o, int Nq, int Nk, int heads, int dh, int b0 = 0, int nb = -1, float* lse = nullptr, int causal = 0) {
     AF_TRY(check(o));
     if (dry) return 0;
     if (nb < 0) nb = o.B;
@@ -795,6 +848,7 @@ struct Runner {
     p.Nq = Nq; p.Nk = Nk; p.H = heads;
     p.scale = 1.0f / sqrtf((float)dh);
     p.lse = lse;
+    p.causal = causal;
     return DISPATCH(dt, af_launch_attention<bf16>(p, nb, dh, s), af_launch_attention<float>(p, nb, dh, s));
   }
   int copy_channels(const Act& src, Act& dst, int off) {
@@ -1325,6 +1379,54 @@ static int vae_encode_impl(af_handle* h, hipStream_t s, const float* x_dev, floa
   return 0;
 }
 
+// text_model_forward after the embedding lookup (encoders/modules.py:299-371): + position embeddings, L pre-LN layers with
+// the causal mask (CLIPEncoderLayer: x += out_proj(attn(LN1 x)); x += fc2(quick_gelu(fc1(LN2 x)))), blend of the last two
+// hidden states, final LayerNorm.
+static int clip_forward_impl(af_handle* h, hipStream_t s, const float* emb_dev, int Bn, int T, float w_prev, float w_last,
+                             float* out_dev) {
+  Runner R(h, s);
+  const af_config& c = h->cfg;
+  const int dt = h->dtype, D = c.clip_hidden, F = c.clip_intermediate, H = c.clip_heads, dh = D / H;
+  R.A.off = 0;
+  Act x = R.alloc_act(Bn, T, 1, D);
+  Act xprev = R.alloc_act(Bn, T, 1, D);
+  Act n = R.alloc_act(Bn, T, 1, D);
+  Act qkv = R.alloc_act(Bn, T, 1, 3 * D);
+  Act a = R.alloc_act(Bn, T, 1, D);
+  Act x1 = R.alloc_act(Bn, T, 1, D);
+  Act f = R.alloc_act(Bn, T, 1, F);
+  AF_TRY(R.check(f));
+  const long rows = (long)Bn * T;
+  if (!R.dry)
+    AF_TRY(DISPATCH(dt, af_launch_add_pos_cast<bf16>(emb_dev, h->clip_pos, T, D, x.p, rows, s),
+                    af_launch_add_pos_cast<float>(emb_dev, h->clip_pos, T, D, x.p, rows, s)));
+  const int L = (int)h->clip_layers.size();
+  for (int i = 0; i < L; ++i) {
+    const ClipLayerW& w = h->clip_layers[i];
+    if (i == L - 1 && !R.dry)   // encoder_states[-2] = the input of the last layer
+      HIP_CHECK_RET(hipMemcpyAsync(xprev.p, x.p, (size_t)rows * D * esize(dt), hipMemcpyDeviceToDevice, s));
+    AF_TRY(R.layernorm(w.ln1, x, n));
+    AF_TRY(R.conv(w.qkv, n, qkv, 1, 0, nullptr, nullptr, 0));
+    AF_TRY(R.attention(qkv.p, 3 * D, (long)T * 3 * D, R.elem_ptr(qkv.p, D), 3 * D, (long)T * 3 * D, R.elem_ptr(qkv.p, 2 * D),
+                       3 * D, (long)T * 3 * D, a, T, T, H, dh, 0, -1, nullptr, /*causal=*/1));
+    AF_TRY(R.conv(w.out, a, x1, 1, 0, &x, nullptr, 0));
+    AF_TRY(R.layernorm(w.ln2, x1, n));
+    AF_TRY(R.conv(w.fc1, n, f, 1, 0, nullptr, nullptr, 0));
+    if (!R.dry)
+      AF_TRY(DISPATCH(dt, af_launch_quick_gelu<bf16>(f.p, f.p, rows * F, s), af_launch_quick_gelu<float>(f.p, f.p, rows * F, s)));
+    AF_TRY(R.conv(w.fc2, f, x, 1, 0, &x1, nullptr, 0));
+  }
+  if (!R.dry) {
+    if (L >= 1)
+      AF_TRY(DISPATCH(dt, af_launch_blend2<bf16>(xprev.p, w_prev, x.p, w_last, n.p, rows * D, s),
+                      af_launch_blend2<float>(xprev.p, w_prev, x.p, w_last, n.p, rows * D, s)));
+  }
+  AF_TRY(R.layernorm(h->clip_final_ln, L >= 1 ? n : x, a));
+  if (!R.dry)
+    AF_TRY(DISPATCH(dt, af_launch_cast_to_f32<bf16>(a.p, out_dev, rows * D, s), af_launch_cast_to_f32<float>(a.p, out_dev, rows * D, s)));
+  return 0;
+}
+
 // ============================================================================
 // C ABI
 // ============================================================================
@@ -1359,6 +1461,11 @@ int af_create(int device_id, const af_config* cfg, af_handle** out) {
       rc = build_vae_encoder(b);
       if (rc) { af_destroy(h.release()); return rc; }
     }
+  }
+  if (cfg->build_clip) {
+    if (cfg->clip_vocab <= 0 || cfg->clip_layers <= 0 || cfg->clip_max_pos <= 0) { af_set_error_msg("af_create: bad CLIP config"); return AF_ERR_INVALID; }
+    int rc = build_clip(b);
+    if (rc) { af_destroy(h.release()); return rc; }
   }
   if (b.rc) { af_destroy(h.release()); return b.rc; }
   HIP_CHECK_RET(hipDeviceSynchronize());
@@ -1438,7 +1545,9 @@ static int load_tensor_impl(af_handle* h, const char* name, const float* host_da
     HIP_CHECK_RET(hipMemcpy(h->stage, host_data, bytes, hipMemcpyHostToDevice));
     srcp = h->stage;
   }
-  if (s.kind == Slot::WEIGHT) {
+  if (s.kind == Slot::TABLE) {
+    AF_TRY(DISPATCH(h->dtype, af_launch_cast_f32<bf16>(srcp, s.dst, (long)n, 0), af_launch_cast_f32<float>(srcp, s.dst, (long)n, 0)));
+  } else if (s.kind == Slot::WEIGHT) {
     AF_TRY(DISPATCH(h->dtype,
                     af_launch_repack_weight<bf16>(srcp, s.dst, s.rows, s.cin, s.cin_pad, s.ks, s.ldw, s.row_off, s.perm, 0),
                     af_launch_repack_weight<float>(srcp, s.dst, s.rows, s.cin, s.cin_pad, s.ks, s.ldw, s.row_off, s.perm, 0)));
@@ -1622,6 +1731,33 @@ int af_unet_set_tap(af_handle* h, int block, float* out_dev) {
   h->tap_index = (block >= 0 && out_dev) ? block : -1;
   h->tap_out = h->tap_index >= 0 ? out_dev : nullptr;
   return AF_OK;
+}
+
+int af_clip_embed_tokens(af_handle* h, const int64_t* ids_dev, int64_t n, float* emb_dev, void* stream) {
+  if (!h || !ids_dev || !emb_dev || n <= 0) { af_set_error_msg("af_clip_embed_tokens: bad argument"); return AF_ERR_INVALID; }
+  if (!h->cfg.build_clip) { af_set_error_msg("af_clip_embed_tokens: handle has no CLIP text tower"); return AF_ERR_STATE; }
+  HIP_CHECK_RET(hipSetDevice(h->device));
+  AF_TRY(check_loaded(h, "cond_stage_model.transformer.text_model.embeddings.token_embedding."));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return DISPATCH(h->dtype,
+                  af_launch_embed_rows<bf16>((const long long*)ids_dev, h->clip_tok, h->cfg.clip_vocab, h->cfg.clip_hidden, emb_dev, (long)n, s),
+                  af_launch_embed_rows<float>((const long long*)ids_dev, h->clip_tok, h->cfg.clip_vocab, h->cfg.clip_hidden, emb_dev, (long)n, s));
+}
+
+int af_clip_text_forward(af_handle* h, const float* inputs_embeds_dev, int Bn, int T, float w_prev, float w_last,
+                         float* out_dev, void* stream) {
+  if (!h || !inputs_embeds_dev || !out_dev || Bn <= 0 || T <= 0) { af_set_error_msg("af_clip_text_forward: bad argument"); return AF_ERR_INVALID; }
+  if (!h->cfg.build_clip) { af_set_error_msg("af_clip_text_forward: handle has no CLIP text tower"); return AF_ERR_STATE; }
+  if (T > h->cfg.clip_max_pos) { af_set_error_msg("af_clip_text_forward: %d tokens but only %d positions", T, h->cfg.clip_max_pos); return AF_ERR_INVALID; }
+  HIP_CHECK_RET(hipSetDevice(h->device));
+  AF_TRY(check_loaded(h, "cond_stage_model.transformer.text_model."));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  h->arena.dry = true; h->arena.peak = 0;
+  int rc = clip_forward_impl(h, s, inputs_embeds_dev, Bn, T, w_prev, w_last, out_dev);
+  h->arena.dry = false;
+  if (rc) return rc;
+  if (h->arena.peak > h->arena.cap) { HIP_CHECK_RET(hipStreamSynchronize(s)); AF_TRY(ensure_arena(h, h->arena.peak)); }
+  return clip_forward_impl(h, s, inputs_embeds_dev, Bn, T, w_prev, w_last, out_dev);
 }
 
 int af_ddim_step(const float* x_dev, const float* eps_cond_dev, const float* eps_uncond_dev, const float* noise_dev,

@@ -170,7 +170,7 @@ int af_op_layernorm(int dtype, const float* x_dev, const float* gamma_dev, const
 }
 
 int af_op_attention(int dtype, const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int B, int Nq,
-                    int Nk, int heads, int dh, float scale, void* stream) {
+                    int Nk, int heads, int dh, float scale, int causal, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Tmp tmp;
   const int C = heads * dh;
@@ -183,7 +183,7 @@ int af_op_attention(int dtype, const float* q_dev, const float* k_dev, const flo
   OP_TRY(DISP(dtype, af_launch_cast_f32<bf16>(k_dev, kn, nk, s), af_launch_cast_f32<float>(k_dev, kn, nk, s)));
   OP_TRY(DISP(dtype, af_launch_cast_f32<bf16>(v_dev, vn, nk, s), af_launch_cast_f32<float>(v_dev, vn, nk, s)));
   AttnParams p;
-  p.q = qn; p.k = kn; p.v = vn; p.o = on; p.lse = nullptr;
+  p.q = qn; p.k = kn; p.v = vn; p.o = on; p.lse = nullptr; p.causal = causal;
   p.ldq = p.ldk = p.ldv = p.ldo = C;
   p.bsq = (long)Nq * C; p.bso = (long)Nq * C; p.bsk = (long)Nk * C; p.bsv = (long)Nk * C;
   p.Nq = Nq; p.Nk = Nk; p.H = heads; p.scale = scale;

@@ -26,7 +26,8 @@ def _fill(arr, values: Sequence[int]):
 
 
 class Engine:
-    def __init__(self, *, dtype: str = "bf16", device: int = 0, unet: Optional[dict] = None, vae: Optional[dict] = None):
+    def __init__(self, *, dtype: str = "bf16", device: int = 0, unet: Optional[dict] = None, vae: Optional[dict] = None,
+                 clip: Optional[dict] = None):
         """unet: UNetModel ctor kwargs (in_channels, model_channels, out_channels, num_res_blocks,
         attention_resolutions, channel_mult, num_heads, context_dim, transformer_depth);
         vae: Decoder ddconfig (ch, out_ch, ch_mult, num_res_blocks, z_channels) + embed_dim."""
@@ -67,7 +68,11 @@ class Engine:
             if vae.get("encoder", False):
                 cfg.build_vae_encoder = 1
                 cfg.vae_in_channels = vae.get("in_channels", 3)
-        self.unet_cfg, self.vae_cfg = unet, vae
+        if clip is not None:   # CLIP text tower (vocab, hidden, layers, heads, intermediate, max_pos)
+            cfg.build_clip = 1
+            cfg.clip_vocab, cfg.clip_hidden, cfg.clip_layers = clip["vocab"], clip["hidden"], clip["layers"]
+            cfg.clip_heads, cfg.clip_intermediate, cfg.clip_max_pos = clip["heads"], clip["intermediate"], clip["max_pos"]
+        self.unet_cfg, self.vae_cfg, self.clip_cfg = unet, vae, clip
         torch.cuda.init()
         check(self._lib.af_create(device, C.byref(cfg), C.byref(self._h)), "af_create")
         self._ctx_key = None
@@ -202,6 +207,25 @@ class Engine:
         check(self._lib.af_posterior_sample(ptr(moments), ptr(nz), float(scale), ptr(z), B, C2 // 2, H * W, stream_ptr()),
               "af_posterior_sample")
         return z
+
+    # -- conditioning producer (CLIP text tower) --------------------------------------------
+    def clip_embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
+        """token_embedding(input_ids): int64 [B, T] device tensor -> fp32 [B, T, hidden]."""
+        ids = ids.contiguous().long()
+        out = torch.empty(*ids.shape, self.clip_cfg["hidden"], device=ids.device, dtype=torch.float32)
+        check(self._lib.af_clip_embed_tokens(self._h, ptr(ids), ids.numel(), ptr(out), stream_ptr()), "af_clip_embed_tokens")
+        return out
+
+    def clip_text_forward(self, inputs_embeds: torch.Tensor, w_prev: float = 0.5, w_last: float = 0.5) -> torch.Tensor:
+        """inputs_embeds fp32 [Bn, T, hidden] (before the position embeddings) -> blended, final-LayerNormed states."""
+        x = inputs_embeds.contiguous().float()
+        Bn, T, D = x.shape
+        if D != self.clip_cfg["hidden"]:
+            raise ValueError(f"inputs_embeds width {D} != hidden {self.clip_cfg['hidden']}")
+        out = torch.empty_like(x)
+        check(self._lib.af_clip_text_forward(self._h, ptr(x), Bn, T, float(w_prev), float(w_last), ptr(out), stream_ptr()),
+              "af_clip_text_forward")
+        return out
 
     def arena_bytes(self) -> int:
         return int(self._lib.af_arena_bytes(self._h))

@@ -191,3 +191,26 @@ def vae_encoder_param_shapes(*, ch, ch_mult, num_res_blocks, z_channels, in_chan
     wb("norm_out", (block_in,))
     wb("conv_out", (2 * z_channels, block_in, 3, 3))
     return shapes
+
+
+def clip_text_param_shapes(vocab: int, hidden: int, layers: int, heads: int, intermediate: int, max_pos: int) -> Dict[str, Shape]:
+    """state_dict keys of transformers CLIPTextModel.text_model (the reference's cond_stage_model.transformer.text_model,
+    encoders/modules.py:185), relative to `text_model.`."""
+    D, Fm = hidden, intermediate
+    out: Dict[str, Shape] = {"embeddings.token_embedding.weight": (vocab, D),
+                             "embeddings.position_embedding.weight": (max_pos, D)}
+    for i in range(layers):
+        p = f"encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            out[p + f"self_attn.{n}.weight"] = (D, D)
+            out[p + f"self_attn.{n}.bias"] = (D,)
+        for n in ("layer_norm1", "layer_norm2"):
+            out[p + n + ".weight"] = (D,)
+            out[p + n + ".bias"] = (D,)
+        out[p + "mlp.fc1.weight"] = (Fm, D)
+        out[p + "mlp.fc1.bias"] = (Fm,)
+        out[p + "mlp.fc2.weight"] = (D, Fm)
+        out[p + "mlp.fc2.bias"] = (D,)
+    out["final_layer_norm.weight"] = (D,)
+    out["final_layer_norm.bias"] = (D,)
+    return out

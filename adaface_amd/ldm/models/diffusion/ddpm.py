@@ -4,9 +4,9 @@ LatentDiffusion the denoising path touches — model assembly from the yaml conf
 DiffusionWrapper.forward (:5477-5516), decode_first_stage (:1251-1308), ema_scope (:310-323),
 q_sample (:478-482).  ~4.5k lines of training losses are out of scope.
 
-The text side (FrozenCLIPEmbedder, EmbeddingManager) cannot be built offline
-(SURVEY.md §8c); get_learned_conditioning therefore accepts pre-computed prompt
-embeddings and otherwise raises with that explanation.
+The text side: cond_stage_model = the FrozenCLIPEmbedder drop-in (CLIP text tower on the HIP kernels),
+embedding_manager = the inference subset of EmbeddingManager.  get_learned_conditioning takes prompts (needs a tokenizer,
+whose vocabulary files do not exist offline), token-id tensors, or a pre-computed static prompt embedding.
 """
 from __future__ import annotations
 
@@ -115,12 +115,25 @@ class LatentDiffusion(DDPM):
         self.cond_stage_trainable = cond_stage_trainable
         self.scale_factor = scale_factor
         self.first_stage_model = instantiate_from_config(first_stage_config).eval()
-        # The CLIP text tower and the EmbeddingManager need weights/tokenizer files that do not exist
-        # offline (encoders/modules.py:184-185, subj_basis_generator.py:22); they are optional here.
-        self.cond_stage_model = None
-        self.embedding_manager = None
+        # ddpm.py:808-813, 860-880: the conditioning producer.  Constructed like the reference does so that the
+        # `cond_stage_model.*` entries of an SD checkpoint load; its HIP engine is only created on first use.
         self.cond_stage_config = cond_stage_config
         self.personalization_config = personalization_config
+        self.cond_stage_forward = cond_stage_forward
+        self.cond_stage_model = None
+        if isinstance(cond_stage_config, dict) and "target" in cond_stage_config:
+            self.cond_stage_model = instantiate_from_config(cond_stage_config).eval()
+        self.embedding_manager = None
+        if self.cond_stage_model is not None:
+            from adaface_amd.ldm.modules.embedding_manager import EmbeddingManager
+            if isinstance(personalization_config, dict) and "target" in personalization_config:
+                pc = dict(personalization_config.get("params", None) or {})
+                pc.pop("embedding_manager_ckpt", None)
+                self.embedding_manager = EmbeddingManager(self.cond_stage_model, **pc)
+            else:
+                self.embedding_manager = EmbeddingManager(self.cond_stage_model, subject_strings=[])
+        self.compel_cfg_weight_level_range = None
+        self.apply_compel_cfg_prob = 0
         self.empty_context = None
 
     # ---- conditioning ------------------------------------------------------------------------
@@ -130,7 +143,7 @@ class LatentDiffusion(DDPM):
         """ddpm.py:962-1076.  Accepts a pre-computed static prompt embedding tensor [B*16,77,768] (or
         [B,77,768], replicated over the 16 layers like embedding_manager.py:1342-1353) and wraps it into the
         (emb, prompts, extra_info) tuple the sampler and the UNet expect (ddpm.py:1056-1069)."""
-        if isinstance(cond_in, torch.Tensor):
+        if isinstance(cond_in, torch.Tensor) and cond_in.is_floating_point():
             emb = cond_in
             if self.use_layerwise_embedding and emb.dim() == 3 and emb.shape[0] % self.N_CA_LAYERS != 0:
                 raise ValueError("layerwise embedding must have batch divisible by 16")
@@ -140,9 +153,31 @@ class LatentDiffusion(DDPM):
                           'compel_cfg_weight_level_range': None, 'apply_compel_cfg_prob': 0,
                           'empty_context': self.empty_context, 'capture_distill_attn': False}
             return (emb, prompts, extra_info)
-        raise NotImplementedError(
-            "text -> embedding needs FrozenCLIPEmbedder weights (openai/clip-vit-large-patch14) which are not "
-            "available offline; pass a pre-computed embedding tensor (SURVEY.md §8c, §8f-2)")
+        # prompts (list of str) or token ids (int64 [B, 77]): the reference's flow, ddpm.py:966-1069
+        if zs_clip_features is not None or zs_id_embs is not None or apply_arc2face_inverse_embs or apply_arc2face_embs:
+            raise NotImplementedError("zero-shot identity conditioning (Arc2Face / SubjBasisGenerator) is not built: "
+                                      "SURVEY.md §8f-4, weight-blocked offline")
+        if self.cond_stage_model is None:
+            raise RuntimeError("this LatentDiffusion was built without a cond_stage_config: pass an embedding tensor")
+        self.cond_stage_model.device = self.device
+        if self.empty_context is not None:
+            self.empty_context = self.empty_context.to(self.device)
+        if randomize_clip_weights:
+            self.cond_stage_model.sample_last_layers_skip_weights()
+        self.embedding_manager.set_curr_iter_type(embman_iter_type or 'recon_iter')
+        static_prompt_embedding = self.cond_stage_model.encode(cond_in, embedding_manager=self.embedding_manager)
+        import copy
+        extra_info = {'use_layerwise_context': self.use_layerwise_embedding,
+                      'use_conv_attn_kernel_size': self.embedding_manager.use_conv_attn_kernel_size,
+                      'placeholder2indices': copy.copy(self.embedding_manager.placeholder2indices),
+                      'prompt_emb_mask': copy.copy(self.embedding_manager.prompt_emb_mask),
+                      'is_training': self.embedding_manager.training,
+                      'compel_cfg_weight_level_range': self.compel_cfg_weight_level_range,
+                      'apply_compel_cfg_prob': self.apply_compel_cfg_prob,
+                      'empty_context': self.empty_context,
+                      'capture_distill_attn': False}
+        prompts = list(cond_in) if not isinstance(cond_in, torch.Tensor) else [""] * cond_in.shape[0]
+        return (static_prompt_embedding, prompts, extra_info)
 
     @staticmethod
     def layerwise_repeat(emb, n_layers=16):
@@ -195,4 +230,6 @@ class LatentDiffusion(DDPM):
     def set_compute_dtype(self, dtype: str):
         self.model.diffusion_model.set_compute_dtype(dtype)
         self.first_stage_model.set_compute_dtype(dtype)
+        if self.cond_stage_model is not None:
+            self.cond_stage_model.set_compute_dtype(dtype)
         return self

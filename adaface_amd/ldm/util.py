@@ -36,6 +36,7 @@ _TARGET_ALIASES = {
     "ldm.modules.diffusionmodules.openaimodel.UNetModel": "adaface_amd.ldm.modules.diffusionmodules.openaimodel.UNetModel",
     "ldm.models.autoencoder.AutoencoderKL": "adaface_amd.ldm.models.autoencoder.AutoencoderKL",
     "ldm.modules.embedding_manager.EmbeddingManager": "adaface_amd.ldm.modules.embedding_manager.EmbeddingManager",
+    "ldm.modules.encoders.modules.FrozenCLIPEmbedder": "adaface_amd.ldm.modules.encoders.modules.FrozenCLIPEmbedder",
 }
 
 

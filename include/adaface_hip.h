@@ -51,6 +51,11 @@ typedef struct af_config {
   /* VAE encoder (init-image path: Encoder model.py:408-499 + quant_conv autoencoder.py:304); needs build_vae */
   int build_vae_encoder;
   int vae_in_channels;            /* 3 */
+  /* CLIP text tower = FrozenCLIPEmbedder.transformer (ldm/modules/encoders/modules.py:179-463; transformers
+   * CLIPTextModel: openai/clip-vit-large-patch14 = vocab 49408, hidden 768, 12 layers, 12 heads, intermediate 3072,
+   * 77 positions, quick_gelu) — the conditioning producer in front of the path */
+  int build_clip;
+  int clip_vocab, clip_hidden, clip_layers, clip_heads, clip_intermediate, clip_max_pos;
 } af_config;
 
 const char* af_last_error(void);
@@ -89,6 +94,18 @@ int af_set_context(af_handle* h, const float* ctx_dev, int Bf, int n_tokens, int
  * t_dev [Bf] int64, eps_dev [Bf,Cout,H,W] fp32 NCHW.  Uses the context set above. */
 int af_unet_forward(af_handle* h, const float* x_dev, const int64_t* t_dev, float* eps_dev, int Bf, int H, int W,
                     void* stream);
+
+/* ---- conditioning producer: CLIP text tower (names "cond_stage_model.transformer.text_model.<k>") ----
+ * af_clip_embed_tokens = CLIPTextEmbeddings.token_embedding (encoders/modules.py:207-208): ids_dev [n] int64 ->
+ *   emb_dev [n, hidden] fp32.  The caller (EmbeddingManager.forward, embedding_manager.py:1292-1584) patches the
+ *   placeholder rows and tucks the 16 layer copies into the batch axis before the encoder runs.
+ * af_clip_text_forward = the rest of text_model_forward (encoders/modules.py:299-371): + position embeddings, the
+ *   causally masked pre-LN transformer layers, the weighted sum of the LAST TWO hidden states (w_prev for the input of
+ *   the last layer, w_last for its output; the reference's default is 0.5 / 0.5), final_layer_norm.
+ *   inputs_embeds_dev [Bn, T, hidden] fp32 -> out_dev [Bn, T, hidden] fp32. */
+int af_clip_embed_tokens(af_handle* h, const int64_t* ids_dev, int64_t n, float* emb_dev, void* stream);
+int af_clip_text_forward(af_handle* h, const float* inputs_embeds_dev, int Bn, int T, float w_prev, float w_last,
+                         float* out_dev, void* stream);
 
 /* Diagnostic tap on the U-Net's block outputs (what a forward hook on input_blocks[i] / middle_block / output_blocks[j]
  * of the reference UNetModel sees, openaimodel.py:984-1027): blocks are numbered in forward order, input_blocks
@@ -183,9 +200,10 @@ int af_op_groupnorm(int dtype, const float* x_dev, const float* gamma_dev, const
 /* F.layer_norm over the last dim of [rows, C]. */
 int af_op_layernorm(int dtype, const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps,
                     float* y_dev, int64_t rows, int C, void* stream);
-/* multi-head attention on [B,N,heads*dh] / [B,S,heads*dh] tensors (attention.py:197-243). */
+/* multi-head attention on [B,N,heads*dh] / [B,S,heads*dh] tensors (attention.py:197-243); causal != 0: query i sees
+ * keys <= i (CLIP text tower). */
 int af_op_attention(int dtype, const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int B, int Nq,
-                    int Nk, int heads, int dh, float scale, void* stream);
+                    int Nk, int heads, int dh, float scale, int causal, void* stream);
 /* timestep_embedding (util.py:154-174): t [B] int64 -> y [B,dim] fp32. */
 int af_op_timestep_embedding(int dtype, const int64_t* t_dev, float* y_dev, int B, int dim, void* stream);
 

@@ -206,8 +206,10 @@ def test_out_of_scope_branches_raise(gpu, tiny_model):
     short = dict(info, use_conv_attn_kernel_size=3, placeholder2indices={"z": (torch.tensor([0]), torch.tensor([1]))})
     with pytest.raises(ValueError):   # one embedding cannot cover a 3x3 kernel (util.py:732)
         tiny_model.apply_model(x, t, (emb, prompts, short))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="vocabulary files are not available"):   # no tokenizer files offline
         tiny_model.get_learned_conditioning(["a photo of a z"])
+    with pytest.raises(NotImplementedError):                                         # zero-shot identity path: not built
+        tiny_model.get_learned_conditioning(["a photo of a z"], zs_id_embs=torch.zeros(1, 512))
 
 
 def test_encode_first_stage_matches_reference(gpu, report, tiny_model):

@@ -210,3 +210,29 @@ def test_reference_module_goldens(tiny):
     close(O._conv(mp("down", "d."), "d.op", x, stride=2), "op_downsample")
     close(O._conv(mp("up", "u."), "u.conv", F.interpolate(x, scale_factor=2, mode="nearest")), "op_upsample")
     close(O.spatial_transformer(mp("st", "s."), "s", x, T("op_st_ctx"), 2, 1), "op_spatial_transformer")
+
+
+# ------------------------------------------------------------------ CLIP text tower ----------
+def test_clip_oracle_matches_transformers_golden():
+    """oracle/clip_oracle.py against a randomly initialised transformers.CLIPTextModel driven like the reference's
+    patched forwards (tests/golden/gen_golden_clip.py): plain prompts, another last-layers blend, a batch whose token
+    embeddings the EmbeddingManager restatement patched (48 = 3 x 16 layer copies), and the full-size tower."""
+    from oracle import clip_oracle as CO
+    g = dict(np.load(GOLD / "golden_clip.npz"))
+    cfg = CO.TINY_CLIP
+    sd = O.synth_state_dict(CO.clip_param_shapes(cfg), seed=41)
+    ids = torch.tensor(g["tiny_ids"])
+    z = CO.clip_text_forward(sd, cfg, CO.clip_embed_tokens(sd, ids))
+    assert np.abs(z.numpy() - g["tiny_z"]).max() < 2e-5 * np.abs(g["tiny_z"]).max()
+    z = CO.clip_text_forward(sd, cfg, CO.clip_embed_tokens(sd, ids), skip_weights=(0.2, 0.8))
+    assert np.abs(z.numpy() - g["tiny_z_w28"]).max() < 2e-5 * np.abs(g["tiny_z_w28"]).max()
+    assert np.abs(g["tiny_z_w28"] - g["tiny_z"]).max() > 1e-3          # the blend weights matter
+    ids_p = torch.tensor(g["tiny_ids_subj"])
+    patched, ph, mask = CO.embedding_manager_patch(ids_p, CO.clip_embed_tokens(sd, ids_p), 777, torch.tensor(g["tiny_subj_emb"]))
+    z = CO.clip_text_forward(sd, cfg, patched)
+    assert z.shape == (48, 77, 64) and np.abs(z.numpy() - g["tiny_z_subj"]).max() < 2e-5 * np.abs(g["tiny_z_subj"]).max()
+    cfg = CO.SD15_CLIP
+    sd = O.synth_state_dict(CO.clip_param_shapes(cfg), seed=42)
+    z = CO.clip_text_forward(sd, cfg, CO.clip_embed_tokens(sd, torch.tensor(g["sd15_ids"])))
+    assert np.abs(z.numpy() - g["sd15_z"]).max() < 5e-5 * np.abs(g["sd15_z"]).max()
+    assert sum(int(np.prod(s)) for s in CO.clip_param_shapes(cfg).values()) == 123_060_480   # CLIP ViT-L/14 text tower
