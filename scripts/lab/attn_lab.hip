@@ -621,6 +621,16 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4
   wait_keep(min(D, nt) - 1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if constexpr ((FLAGS & (256 | 512 | 1024)) != 0) {
+    // de-synchronise the workgroups that share a CU: the one in the upper wave slots starts part of a tile period late
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    const bool late = (FLAGS & 1024) ? ((blockIdx.x + blockIdx.y) & 1) : (((hwid & 0xF) >> (WAVES == 8 ? 1 : 0)) & 1);
+    if (late) {
+      if constexpr ((FLAGS & 256) != 0) __builtin_amdgcn_s_sleep(6);     // ~384 cycles
+      if constexpr ((FLAGS & 512) != 0) __builtin_amdgcn_s_sleep(12);    // ~768 cycles
+    }
+  }
   int rb = 0, wb = D % NBUF;   // ring slots of tile t and of tile t + D
 
   for (int t = 0; t < nt; ++t) {
@@ -1129,6 +1139,12 @@ int main(int argc, char** argv) {
       {"HA3 ring 8x3 head-major no QK", launch_ring<1 | 16, 8, 3>, false, true},
       {"HV0 shipped kernel on head-major", launch<0, 4>, true, true},
       {"R3p ring 8x2 setprio around MFMA", launch_ring<1 | 64, 8, 2>, true},
+      {"S1 ring 8x2 stagger 384 by wave slot", launch_ring<1 | 256, 8, 2>, true},
+      {"S2 ring 8x2 stagger 768 by wave slot", launch_ring<1 | 512, 8, 2>, true},
+      {"S3 ring 8x2 stagger 1152 by wave slot", launch_ring<1 | 256 | 512, 8, 2>, true},
+      {"S4 ring 8x2 stagger 384 by block parity", launch_ring<1 | 256 | 1024, 8, 2>, true},
+      {"S5 ring 4x2 stagger 384 by wave slot", launch_ring<1 | 256, 4, 2>, true},
+      {"S6 ring 4x2 stagger 768 by wave slot", launch_ring<1 | 512, 4, 2>, true},
       {"R3x ring 8x2 xcd", launch_ring<3, 8, 2>, true},
       {"R4x ring 8x3 xcd", launch_ring<3, 8, 3>, true},
       {"R5x ring 8x4 xcd", launch_ring<3, 8, 4>, true},
