@@ -86,6 +86,10 @@ _SIGS = [
     ("af_op_conv2d", C.c_int, [C.c_int, _P, _P, _P, _P, _P] + [C.c_int] * 9 + [_P]),
     ("af_op_linear", C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     ("af_op_groupnorm", C.c_int, [C.c_int, _P, _P, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    ("af_set_fp8", C.c_int, [_P, C.c_int]),
+    ("af_fp8_gemm_launches", C.c_int64, []),
+    ("af_op_conv2d_fp8", C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 10 + [_P]),
+    ("af_op_groupnorm_fp8", C.c_int, [_P, _P, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("af_op_layernorm", C.c_int, [C.c_int, _P, _P, _P, C.c_float, _P, C.c_int64, C.c_int, _P]),
     ("af_op_attention", C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
     ("af_clip_embed_tokens", C.c_int, [_P, _P, C.c_int64, _P, _P]),
@@ -131,10 +135,11 @@ def plan_counts(reset: bool = False) -> dict:
     lib = load()
     c = (C.c_int64 * 10)()
     check(lib.af_gemm_plan_counts(c), "af_gemm_plan_counts")
-    if reset:
-        lib.af_gemm_plan_counts_reset()
     out = {f"tile{i}": int(c[i]) for i in range(6)}
     out["halo"], out["splitk"], out["ln_consumer"], out["ln_producer"] = int(c[6]), int(c[7]), int(c[8]), int(c[9])
+    out["fp8"] = int(lib.af_fp8_gemm_launches())
+    if reset:
+        lib.af_gemm_plan_counts_reset()
     return out
 
 

@@ -42,7 +42,7 @@ static inline int af_ensure_dynamic_lds(unsigned long long& done_mask, const voi
 // classes 5-7 split the eight-wave ping-pong kernel out of the conv/linear class by instantiation, so that the bench can
 // quote ONE kernel (conv_gemm_pp_kernel<160, true>, the 3x3 convolutions) with its own launch count and duration
 enum { AF_K_CONV_GEMM = 0, AF_K_ATTENTION = 1, AF_K_GROUPNORM = 2, AF_K_LAYERNORM = 3, AF_K_OTHER = 4,
-       AF_K_PP160_GATHER = 5, AF_K_PP160_PLAIN = 6, AF_K_PP128 = 7, AF_K_COUNT = 8 };
+       AF_K_PP160_GATHER = 5, AF_K_PP160_PLAIN = 6, AF_K_PP128 = 7, AF_K_PP_FP8 = 8, AF_K_COUNT = 9 };
 extern int g_af_prof_enabled;
 extern int g_af_prof_stride;              // bracket only every stride-th launch of a class (>= 1)
 extern long g_af_prof_seen[AF_K_COUNT];   // launches seen per class since af_prof_reset
@@ -239,6 +239,14 @@ struct ConvGemmParams {
   int k_tap_inner;        // ping-pong kernel (set by the launcher): K walked as (channel chunk, tap) instead of (tap, chunk)
   int pp_epilogue;        // ping-pong kernel (set by the launcher): 0 = direct for GEGLU / split-K slabs and LDS
                           // otherwise, 1 = always through LDS, 2 = always direct
+  // fp8 (OCP e4m3) operands on the block-scaled MFMA (ping-pong kernel only; bf16 in every other respect: bias,
+  // residual, output).  src = fp8 NHWC (ldc, src_batch_stride in BYTES), W = fp8 [Wrows][ldw] with K laid out in 64-channel
+  // UNITS, unit u = (channel chunk u / taps, tap u % taps), zero-padded to a multiple of 128 = K; Cin = real channel
+  // count (multiple of 64).  Scales are powers of two applied by the MFMA itself (E8M0): w_scale[n] per output channel,
+  // x_scale_e8 for the whole activation tensor (the producer multiplied by 2^(127 - x_scale_e8)).
+  int fp8;
+  const unsigned char* w_scale;
+  int x_scale_e8;
 };
 
 struct AfGemmPlan {

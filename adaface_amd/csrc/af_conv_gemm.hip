@@ -485,12 +485,31 @@ __device__ __forceinline__ void pp_wait_lgkm0() {
   __builtin_amdgcn_sched_barrier(0);   // hipcc hoists register-only MFMAs over an asm wait without this
 }
 
+template <int N> __device__ __forceinline__ void pp_wait_lgkm() {   // counted: LDS reads return in order
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+typedef __attribute__((ext_vector_type(8))) int pp_i32x8;
+typedef __attribute__((ext_vector_type(4))) int pp_i32x4;
+
 // LNMODE: 0 = plain, 1 = LayerNorm consumer (A = un-normalised rows, epilogue applies mu / rstd), 2 = LayerNorm-statistics
 // producer (direct epilogue + per-row partial sums); separate instantiations so that the plain kernel's code is untouched
-template <int BN, bool GATHER, int LNMODE = 0>
+//
+// FP8: both operands are OCP e4m3 bytes and the K tile is 128 values (the same 128-byte LDS rows, pieces, swizzle and
+// fragment reads as bf16), multiplied by v_mfma_scale_f32_16x16x128_f8f6f4 (twice the bf16 MFMA rate) with power-of-two
+// scales per weight row / per activation tensor in the instruction's E8M0 operands.  A lane's 32 operand bytes are the
+// 16-byte chunks q and q + 4 of its row (q = lane >> 4): any 32 of the row's 128 K values will do as long as the weight
+// lane and the activation lane of a lane group hold the same ones, and (q, q + 4) is the conflict-free ds_read_b128 pair
+// the bf16 kernel already uses.  A K tile is two 64-channel UNITS (unit u = channel chunk u / taps, tap u % taps), so
+// that channel counts that are multiples of 64 but not of 128 (320, 960) waste nothing: chunks 0-3 of an LDS row come
+// from unit 2t, chunks 4-7 from unit 2t + 1, each lane of the staging waves walks the units of ITS half.
+template <int BN, bool GATHER, int LNMODE = 0, bool FP8 = false>
 __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams p) {
   using C = PpCfg<BN>;
   typedef bf16 T;
+  static_assert(!FP8 || LNMODE == 0, "fp8 operands: plain epilogue only");
+  constexpr unsigned XE = FP8 ? 1u : 2u;   // bytes per operand element
   constexpr int NI = C::NI, MI = C::MI, SLOT = C::SLOT, XBYTES = C::XBYTES;
   constexpr int NP0 = C::NP0, NX1 = C::NX1, NW1 = C::NW1, NP1 = C::NP1, NPMAX = C::NPMAX, XP0 = C::XP0;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -509,7 +528,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
       const_cast<T*>(reinterpret_cast<const T*>(p.W)), 0, (int)0xFFFFFFF0u, 0x00020000);
 
   // K range of this block (split-K slices)
-  const int KT_all = p.K / 64;
+  const int KT_all = p.K / (FP8 ? 128 : 64);
   const int kt_per = (KT_all + p.splitk - 1) / p.splitk;
   const int kt_begin = zk * kt_per;
   const int KT = min(KT_all, kt_begin + kt_per) - kt_begin;
@@ -518,9 +537,10 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
   // piece XP0 + wq + 4q (q < NX1), then weight piece wq + 4(q - NX1).  Lane: row lane>>3 of the piece, LDS slot
   // lane&7, which receives data chunk (lane&7) ^ (row&7).
   const int srow = lane >> 3;
-  const unsigned lchunk = (unsigned)((lane & 7) ^ srow) * 16u;
+  const unsigned dchunk = (unsigned)((lane & 7) ^ srow);            // data chunk of the 128-byte row this lane fills
+  const unsigned lchunk = (FP8 ? (dchunk & 3u) : dchunk) * 16u;     // ... its byte offset inside the 64-channel run
   const int HoWo = p.Ho * p.Wo;
-  const unsigned ldcb = (unsigned)p.ldc * 2u;
+  const unsigned ldcb = (unsigned)p.ldc * XE;
   unsigned x_off[NP0];
   int x_yx[GATHER ? NP0 : 1];   // (iy0 << 16) | (ix0 & 0xffff): input coordinate of tap (0,0)
   pp_static_for<0, NP0>([&](auto qc) {
@@ -543,7 +563,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
       oy = rem / p.Wo;
       ox = rem - oy * p.Wo;
     }
-    unsigned off = (unsigned)((long)b * p.src_batch_stride * 2) + lchunk;
+    unsigned off = (unsigned)((long)b * p.src_batch_stride * XE) + lchunk;
     if constexpr (GATHER) {
       x_yx[q] = ok ? (((oy * p.stride - p.pad) << 16) | ((ox * p.stride - p.pad) & 0xffff)) : (int)0xC0000000;
     } else {
@@ -556,7 +576,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
 #pragma unroll
   for (int q = 0; q < NW1; ++q) {
     const int n = n0 + (wq + 4 * q) * 8 + srow;
-    w_off[q] = n < p.Wrows ? (unsigned)((long)n * p.ldw * 2) + lchunk : 0xFFFFFFFFu;
+    w_off[q] = n < p.Wrows ? (unsigned)((long)n * p.ldw * XE) + dchunk * 16u : 0xFFFFFFFFu;
   }
   // K order.  The sum over (tap, channel chunk) can be walked either way; with the TAP innermost (k_tap_inner) the nine
   // taps of a channel chunk re-read the same few input rows back to back, so eight of nine gathers hit the XCD's L2
@@ -576,9 +596,29 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     ky = tap / p.ks;
     kx = tap - ky * p.ks;
   }
+  // FP8: (tap, channel offset) of the unit this lane's half of the NEXT tile comes from (per lane: half = dchunk >> 2)
+  const int taps8 = p.ks * p.ks;
+  const int adv_q = 2 / taps8, adv_r = 2 - adv_q * taps8;   // two units further = adv_q chunks + adv_r taps
+  int u_tap = 0, u_c0 = 0;
+  if constexpr (FP8) {
+    const int u = 2 * kt_begin + (int)(dchunk >> 2);
+    const int cc = u / taps8;
+    u_tap = u - cc * taps8;
+    u_c0 = cc * 64;
+  }
   auto x_addr = [&](auto qc) -> unsigned {
     constexpr int q = decltype(qc)::value;
-    if constexpr (GATHER) {
+    if constexpr (FP8) {
+      if constexpr (GATHER) {
+        const int kyl = p.ks == 3 ? (u_tap * 11) >> 5 : 0, kxl = p.ks == 3 ? u_tap - 3 * kyl : 0;
+        const int iy = (x_yx[q] >> 16) + kyl, ix = ((x_yx[q] << 16) >> 16) + kxl;
+        const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && u_c0 < p.Cin;
+        const unsigned pix = (unsigned)((iy >> p.up) * p.Ws + (ix >> p.up));
+        return ok ? x_off[q] + pix * ldcb + (unsigned)u_c0 : 0xFFFFFFFFu;
+      } else {
+        return (u_c0 < p.Cin && x_off[q] != 0xFFFFFFFFu) ? x_off[q] + (unsigned)u_c0 : 0xFFFFFFFFu;
+      }
+    } else if constexpr (GATHER) {
       const int iy = (x_yx[q] >> 16) + ky, ix = ((x_yx[q] << 16) >> 16) + kx;
       const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
       const unsigned pix = (unsigned)((iy >> p.up) * p.Ws + (ix >> p.up));
@@ -588,8 +628,8 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     }
   };
   auto stage = [&](int slot_off) {
-    const unsigned c0b = (unsigned)c0 * 2u;
-    const unsigned k0b = p.k_tap_inner ? (unsigned)((ky * p.ks + kx) * p.Cin + c0) * 2u : (unsigned)ktile * 128u;
+    const unsigned c0b = FP8 ? 0u : (unsigned)c0 * 2u;
+    const unsigned k0b = (!FP8 && p.k_tap_inner) ? (unsigned)((ky * p.ks + kx) * p.Cin + c0) * 2u : (unsigned)ktile * 128u;
     char* base = smem + slot_off;
     pp_static_for<0, NPMAX>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
@@ -601,7 +641,11 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
       }
     });
     ++ktile;
-    if (p.k_tap_inner) {
+    if constexpr (FP8) {
+      u_tap += adv_r;
+      u_c0 += 64 * adv_q;
+      if (u_tap >= taps8) { u_tap -= taps8; u_c0 += 64; }
+    } else if (p.k_tap_inner) {
       if (++kx >= p.ks) {
         kx = 0;
         if (++ky >= p.ks) { ky = 0; c0 += 64; }
@@ -655,11 +699,14 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
   // bias of this lane's output channels (GEGLU: value and gate rows), fetched now so the main loop hides the latency
   const int cl = 4 * (lane >> 4);
   float4 bias_r[NI];
+  auto load_bias = [&]() {
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    bias_r[i] = float4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias && p.splitk <= 1) bias_r[i] = *reinterpret_cast<const float4*>(p.bias + n0 + g * C::HN + i * 16 + cl);
-  }
+    for (int i = 0; i < NI; ++i) {
+      bias_r[i] = float4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias && p.splitk <= 1) bias_r[i] = *reinterpret_cast<const float4*>(p.bias + n0 + g * C::HN + i * 16 + cl);
+    }
+  };
+  if constexpr (!FP8) load_bias();   // (FP8: 104 fragment registers in the loop; the bias is fetched after it)
 
   // LayerNorm consumer: column sums of W * gamma for this lane's channels and mu / rstd of its four rows
   float4 ln_cs[LNMODE == 1 ? NI : 1];
@@ -677,6 +724,81 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     }
   }
 
+  // ---- FP8 fragments and compute phase ----
+  // Order of a tile's 20 (16) MFMAs: weight block outermost, and the LAST weight block's four MFMAs are held back to the
+  // head of the next tile's compute phase, where they cover the latency of that tile's first fragment reads (nothing of
+  // a tile can be read before the barrier that opens its phase).  They need the previous tile's activation fragments, so
+  // those are double-buffered (xa8 / xb8 alternate per tile).  Reads are issued in the order W0 X0 X1 X2 X3 W1 .. W(NI-1):
+  // two blocks up front, then one block (two ds_read_b128) behind each MFMA; every MFMA waits with a counted lgkmcnt for
+  // exactly the blocks it needs (LDS reads return in order).
+  pp_u32x4 w8[FP8 ? NI : 1][2], xa8[FP8 ? MI : 1][2], xb8[FP8 ? MI : 1][2];
+  int wsc8[FP8 ? NI : 1];
+  int xsc8 = p.x_scale_e8;
+  if constexpr (FP8) {
+    // the activation scale as a VGPR made HERE: first used inside the loop, the kernel-argument load behind it would get
+    // its s_waitcnt lgkmcnt(0) in front of the first MFMA of every other tile, draining the fragment reads just issued
+    asm volatile("" : "+v"(xsc8));
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      w8[i][0] = w8[i][1] = pp_u32x4{0u, 0u, 0u, 0u};
+      wsc8[i] = (int)p.w_scale[n0 + g * C::HN + i * 16 + (lane & 15)];
+    }
+#pragma unroll
+    for (int j = 0; j < MI; ++j) xa8[j][0] = xa8[j][1] = xb8[j][0] = xb8[j][1] = pp_u32x4{0u, 0u, 0u, 0u};
+  }
+  auto mfma8 = [&](f32x4& c, const pp_u32x4 (&wv)[2], const pp_u32x4 (&xv)[2], int wscale) {
+    const pp_i32x8 a = __builtin_shufflevector(__builtin_bit_cast(pp_i32x4, wv[0]), __builtin_bit_cast(pp_i32x4, wv[1]), 0, 1, 2, 3, 4, 5, 6, 7);
+    const pp_i32x8 b = __builtin_shufflevector(__builtin_bit_cast(pp_i32x4, xv[0]), __builtin_bit_cast(pp_i32x4, xv[1]), 0, 1, 2, 3, 4, 5, 6, 7);
+    c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, wscale, 0, xsc8);
+    asm volatile("" : "+v"(c));   // a use at this point: hipcc otherwise SINKS the whole tile's MFMAs below the last wait
+  };
+  // counted wait that hands the guarded fragment block through (a data dependency: the MFMA cannot be hoisted over it)
+  auto wait_block = [&](auto nc, pp_u32x4 (&blk)[2]) {
+    constexpr int n = decltype(nc)::value;
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(blk[0]), "+v"(blk[1]) : "n"(n) : "memory");
+  };
+  auto cphase8 = [&](int slot_off, pp_u32x4 (&xc)[FP8 ? MI : 1][2], pp_u32x4 (&xp)[FP8 ? MI : 1][2]) {
+    if constexpr (FP8) {
+      constexpr int NB = NI + MI;
+      const unsigned b0 = lds0 + (unsigned)slot_off + fch0, b1 = lds0 + (unsigned)slot_off + fch1;
+      auto rd_block = [&](auto bc) {
+        constexpr int bi = decltype(bc)::value;
+        if constexpr (bi == 0) {
+          w8[0][0] = pp_lds_read128<0>(b0 + w_base);
+          w8[0][1] = pp_lds_read128<0>(b1 + w_base);
+        } else if constexpr (bi <= MI) {
+          xc[bi - 1][0] = pp_lds_read128<(bi - 1) * 2048>(b0 + x_base);
+          xc[bi - 1][1] = pp_lds_read128<(bi - 1) * 2048>(b1 + x_base);
+        } else {
+          w8[bi - MI][0] = pp_lds_read128<(bi - MI) * 2048>(b0 + w_base);
+          w8[bi - MI][1] = pp_lds_read128<(bi - MI) * 2048>(b1 + w_base);
+        }
+      };
+      rd_block(std::integral_constant<int, 0>{});
+      rd_block(std::integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      pp_static_for<0, MI * NI>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        if constexpr (m < MI) {
+          mfma8(acc[NI - 1][m], w8[NI - 1], xp[m], wsc8[NI - 1]);          // held back from the previous tile
+        } else {
+          constexpr int i = (m - MI) / MI, j = (m - MI) % MI;
+          constexpr int issued = (2 + m) < NB ? (2 + m) : NB;               // blocks issued before this MFMA
+          constexpr int need = i == 0 ? 1 + j : (j == 0 ? MI + i : -1);     // youngest block it reads
+          if constexpr (need >= 0) {
+            std::integral_constant<int, 2 * (issued - need - 1)> cnt;
+            if constexpr (i == 0) wait_block(cnt, xc[j]); else wait_block(cnt, w8[i]);
+            if constexpr (i == 0 && j == 0) wait_block(cnt, w8[0]);
+          }
+          mfma8(acc[i][j], w8[i], xc[j], wsc8[i]);
+        }
+        if constexpr (2 + m < NB) rd_block(std::integral_constant<int, 2 + m>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      pp_wait_lgkm0();       // every read of the tile is back (the last weight block included)
+    }
+  };
+
   // ---- prologue: tile 0 (group 1 also tile 1) in flight; group 1's part of tile 0 landed ----
   stage(0);
   if (g == 1) {
@@ -685,33 +807,65 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
   __builtin_amdgcn_s_barrier();
   if (g == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one interval behind
   int rd = 0, w0 = SLOT, w1 = 2 * SLOT;       // slots of tiles t, t+1, t+2
-  for (int t = 0; t < KT; ++t) {
-    // ---------------- D(t) ----------------
+  auto dphase = [&](int t) {
     if (g == 0) {
       if (t + 1 < KT) { stage(w0); wait_keep1(); } else pp_wait_vm<0>();   // own part of tile t landed
     } else {
       if (t + 2 < KT) stage(w1);
     }
     __builtin_amdgcn_s_barrier();
-    // ---------------- C(t) ----------------
-    __builtin_amdgcn_s_setprio(1);
-    half(rd, U0, U1);      // (t == 0: MFMAs on the zeroed fragments of "unit -1")
-    pp_wait_lgkm0();
-    half(rd, U1, U0);
-    pp_wait_lgkm0();       // every read of tile t is back: the barrier below releases its slot
-    __builtin_amdgcn_s_setprio(0);
+  };
+  auto cend = [&](int t) {
     if (g == 1) { if (t + 2 < KT) wait_keep1(); else pp_wait_vm<0>(); }    // own part of tile t+1 landed
     __builtin_amdgcn_s_barrier();
     const int tmp = rd; rd = w0; w0 = w1; w1 = tmp;
+  };
+  if constexpr (FP8) {
+    for (int t = 0; t < KT; t += 2) {
+      dphase(t);
+      __builtin_amdgcn_s_setprio(1);
+      cphase8(rd, xa8, xb8);
+      __builtin_amdgcn_s_setprio(0);
+      cend(t);
+      if (t + 1 < KT) {
+        dphase(t + 1);
+        __builtin_amdgcn_s_setprio(1);
+        cphase8(rd, xb8, xa8);
+        __builtin_amdgcn_s_setprio(0);
+        cend(t + 1);
+      }
+    }
+    // the last tile's held-back MFMAs
+    if (KT & 1) {
+#pragma unroll
+      for (int j = 0; j < MI; ++j) mfma8(acc[NI - 1][j], w8[NI - 1], xa8[j], wsc8[NI - 1]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < MI; ++j) mfma8(acc[NI - 1][j], w8[NI - 1], xb8[j], wsc8[NI - 1]);
+    }
+  } else {
+    for (int t = 0; t < KT; ++t) {
+      // ---------------- D(t) ----------------
+      dphase(t);
+      // ---------------- C(t) ----------------
+      __builtin_amdgcn_s_setprio(1);
+      half(rd, U0, U1);      // (t == 0: MFMAs on the zeroed fragments of "unit -1")
+      pp_wait_lgkm0();
+      half(rd, U1, U0);
+      pp_wait_lgkm0();       // every read of tile t is back: the barrier below releases its slot
+      __builtin_amdgcn_s_setprio(0);
+      cend(t);
+    }
+    // trailing half tile (unit 2 KT - 1), registers only
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MI; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i][1]),
+                                                            __builtin_bit_cast(bf16x8, xf[j][1]), acc[i][j], 0, 0, 0);
   }
-  // trailing half tile (unit 2 KT - 1), registers only
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < MI; ++j)
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i][1]),
-                                                          __builtin_bit_cast(bf16x8, xf[j][1]), acc[i][j], 0, 0, 0);
   if (g == 0) __builtin_amdgcn_s_barrier();
+  if constexpr (FP8) load_bias();
 
   // ------------------------------- epilogue -------------------------------
   // GEGLU is evaluated in registers by all eight waves first (value block 2k, gate block 2k+1 of the same lane);
@@ -1213,15 +1367,127 @@ int af_launch_ln_finalize(const float* part, int parts, int M, int count, float 
 // ---------------------------------------------------------------------------
 // planning (tile shape + split-K) and launch
 // ---------------------------------------------------------------------------
+// fp8 (OCP e4m3) twin of a repacked bf16 weight [rows][taps * cin_pad] (K order tap, channel): K re-ordered into
+// 64-channel units (unit u = channel chunk u / taps, tap u % taps; zero units up to k8, a multiple of 128) and every row
+// scaled by the power of two that brings its largest magnitude into (224, 448]; sc[row] = E8M0 byte of the inverse.
+__device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f);
+  b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f);
+  d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int v = 0;
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+  return (unsigned)v;
+}
+__global__ __launch_bounds__(256) void quant_weight_fp8_kernel(const bf16* __restrict__ w, int ldw, int cin_pad, int taps,
+                                                                unsigned char* __restrict__ w8, int k8,
+                                                                unsigned char* __restrict__ sc) {
+  __shared__ float s_max[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const bf16* wr = w + (long)row * ldw;
+  float mx = 0.f;
+  for (int k = tid; k < ldw; k += 256) mx = fmaxf(mx, fabsf(to_f32<bf16>(wr[k])));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((tid & 63) == 0) s_max[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+  int e = 0;
+  if (mx > 0.f) {
+    int k;
+    const float m = frexpf(mx, &k);          // mx = m * 2^k, m in [0.5, 1)
+    e = (m <= 0.875f ? 9 : 8) - k;           // largest e with mx * 2^e <= 448 = 0.875 * 2^9
+    e = e < -60 ? -60 : (e > 60 ? 60 : e);
+  }
+  const float mul = ldexpf(1.f, e);
+  if (tid == 0) sc[row] = (unsigned char)(127 - e);
+  unsigned* dst = reinterpret_cast<unsigned*>(w8 + (long)row * k8);
+  for (int q = tid; q < k8 / 4; q += 256) {
+    const int idx = q * 4, u = idx >> 6, i = idx & 63;
+    const int cc = u / taps, tap = u - cc * taps;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cc * 64 < cin_pad) {
+      const bf16* sp = wr + (long)tap * cin_pad + cc * 64 + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = to_f32<bf16>(sp[j]) * mul;
+    }
+    dst[q] = pack4_e4m3(v[0], v[1], v[2], v[3]);
+  }
+}
+int af_launch_quant_weight_fp8(const void* w, int rows, int ldw, int cin_pad, int ks, void* w8, int k8, unsigned char* sc,
+                               hipStream_t stream) {
+  if (cin_pad % 64 != 0 || k8 % 128 != 0 || k8 < ks * ks * cin_pad || ldw != ks * ks * cin_pad) {
+    af_set_error_msg("quant_weight_fp8: cin_pad=%d k8=%d ldw=%d ks=%d", cin_pad, k8, ldw, ks);
+    return -1;
+  }
+  hipLaunchKernelGGL(quant_weight_fp8_kernel, dim3(rows), dim3(256), 0, stream, reinterpret_cast<const bf16*>(w), ldw,
+                     cin_pad, ks * ks, reinterpret_cast<unsigned char*>(w8), k8, sc);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+// bf16 -> e4m3 of x * mul, saturating (operator-level tests; the model's fp8 activations come from the GroupNorm kernels)
+__global__ __launch_bounds__(256) void cast_fp8_kernel(const bf16* __restrict__ x, unsigned* __restrict__ y, long n4, float mul) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    Quad<bf16> q;
+    q.load(x + i * 4);
+    y[i] = pack4_e4m3(to_f32<bf16>(q.e[0]) * mul, to_f32<bf16>(q.e[1]) * mul, to_f32<bf16>(q.e[2]) * mul, to_f32<bf16>(q.e[3]) * mul);
+  }
+}
+int af_launch_cast_fp8(const void* x, void* y, long n, float mul, hipStream_t stream) {
+  if (n % 4 != 0) { af_set_error_msg("cast_fp8: n must be a multiple of 4"); return -1; }
+  unsigned blocks = (unsigned)((n / 4 + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(cast_fp8_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const bf16*>(x),
+                     reinterpret_cast<unsigned*>(y), n / 4, mul);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
 AfGemmPlan g_af_last_plan = {0, 1, 0, 0, 1};
 // launches since af_gemm_plan_counts_reset: [0..5] by tile (implicit-GEMM / ping-pong kernels), [6] LDS-halo kernel,
 // [7] launches that sliced K (counted in their tile's slot as well), [8] / [9] ping-pong launches with the LayerNorm
-// consumer / statistics-producer epilogue
-long g_af_plan_counts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+// consumer / statistics-producer epilogue, [10] ping-pong launches with fp8 operands
+long g_af_plan_counts[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 
 // tile: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64
+static void plan_group_m(AfGemmPlan& pl, const ConvGemmParams& p);
+
+// fp8 operands: the ping-pong kernel or nothing (tile -1: the caller keeps the layer on the bf16 path)
+static AfGemmPlan plan_fp8(const ConvGemmParams& p, int batch) {
+  AfGemmPlan pl;
+  pl.tile = -1;
+  pl.splitk = 1;
+  pl.ws_bytes = 0;
+  pl.halo_tw = 0;
+  pl.group_m = 1;
+  const int cand = p.N % 160 == 0 ? 5 : (p.N % 128 == 0 ? 4 : -1);
+  if (batch != 1 || p.epilogue == AF_EPI_GEGLU || cand < 0 || p.K % 128 != 0 || p.Cin % 64 != 0 || (p.ks != 1 && p.ks != 3) ||
+      p.M < 512 || !g_af_knobs.gemm_pp)
+    return pl;
+  const int KT = p.K / 128;
+  const long nb = (long)((p.M + 255) / 256) * (p.N / (cand == 5 ? 160 : 128));
+  int s = 1;
+  if (nb < 208) {   // slices of >= 8 tiles (a tile is 128 K values here)
+    s = (int)((256 + nb / 2) / nb);
+    if (s > KT / 8) s = KT / 8;
+    if (s > 16) s = 16;
+    if (s < 1) s = 1;
+  }
+  const long nbs = nb * s;
+  const double fill = (double)nbs / (double)(((nbs + 255) / 256) * 256);
+  if (fill < g_af_knobs.gemm_pp_minfill * 0.01) return pl;
+  pl.tile = cand;
+  pl.splitk = s;
+  if (s > 1) pl.ws_bytes = (size_t)s * p.M * p.N * sizeof(float);
+  plan_group_m(pl, p);
+  return pl;
+}
+
 AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) {
+  if (p.fp8) return plan_fp8(p, batch);
   AfGemmPlan pl;
   pl.tile = 0;
   pl.splitk = 1;
@@ -1309,6 +1575,12 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
   if (fs >= 1 && batch == 1 && !geglu) pl.splitk = fs > KT ? KT : fs;
   if (pl.splitk > 1) pl.halo_tw = 0;
   if (pl.splitk > 1) pl.ws_bytes = (size_t)pl.splitk * p.M * p.N * sizeof(float);
+  plan_group_m(pl, p);
+  return pl;
+}
+
+static void plan_group_m(AfGemmPlan& pl, const ConvGemmParams& p) {
+  static const int bm[4] = {128, 64, 128, 64}, bn[4] = {128, 128, 64, 64};
   {
     // grouped tile order: minimise  X_bytes * (NT / gn) + W_bytes * (MT / gm)  with gm * gn = workgroups resident
     // per XCD (32 CUs x blocks per CU)
@@ -1318,7 +1590,7 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
     const int resident = pl.tile >= 4 ? 32 : 32 * ((tbm * tbn >= 128 * 128) ? 2 : 3);
     // activation bytes a column of tiles streams per unit of M: every tap re-reads the input unless the taps of a channel
     // chunk follow each other (LDS halo kernel; ping-pong kernel with the tap innermost: ~1.5x halo rows at stride 1)
-    const bool taps_reuse = pl.halo_tw || (pl.tile >= 4 && p.ks > 1 && g_af_knobs.conv_tap_inner);
+    const bool taps_reuse = pl.halo_tw || (pl.tile >= 4 && p.ks > 1 && (g_af_knobs.conv_tap_inner || p.fp8));
     const double xb = (double)p.M * (p.K / (p.ks * p.ks)) * (taps_reuse ? (p.stride == 1 ? 1.5 : 1.0) : (double)(p.ks * p.ks) / (p.stride * p.stride));
     const double wb = (double)p.N * p.K;
     double bestc = 1e300;
@@ -1333,7 +1605,6 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
     }
     pl.group_m = g_af_knobs.gemm_groupm >= 1 ? g_af_knobs.gemm_groupm : bestg;
   }
-  return pl;
 }
 
 template <typename T, int BM, int BN, bool DMA>
@@ -1380,6 +1651,73 @@ template <int BN> static int launch_pp(const ConvGemmParams& p, hipStream_t stre
   return 0;
 }
 
+template <int BN> static int launch_pp8(const ConvGemmParams& p, hipStream_t stream) {
+  using C = PpCfg<BN>;
+  const bool gather = !(p.ks == 1 && p.pad == 0);
+  static unsigned long long attr_done_g = 0, attr_done_p = 0;
+  if (int rc = af_ensure_dynamic_lds(attr_done_g, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, true, 0, true>), C::LDS_BYTES)) return rc;
+  if (int rc = af_ensure_dynamic_lds(attr_done_p, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, false, 0, true>), C::LDS_BYTES)) return rc;
+  dim3 grid(((p.M + 255) / 256) * (p.N / BN), 1, p.splitk > 1 ? p.splitk : 1);
+  if (gather) hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, true, 0, true>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  else hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, false, 0, true>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// fp8-operand launch (bf16 everywhere else): validated apart from the bf16 / f32 path, ping-pong kernel only
+static int launch_conv_gemm_fp8(ConvGemmParams p, hipStream_t stream, const AfGemmPlan* plan, void* ws) {
+  if (p.K % 128 != 0 || p.Cin % 64 != 0 || (p.ks != 1 && p.ks != 3) || p.K < p.ks * p.ks * p.Cin || p.ldw < p.K ||
+      p.ldw % 16 != 0 || p.ldc % 16 != 0 || p.ldc < p.Cin || !p.w_scale || p.epilogue == AF_EPI_GEGLU || p.ln_stats || p.ln_stats_out) {
+    af_set_error_msg("conv_gemm fp8: K=%d Cin=%d ks=%d ldw=%d ldc=%d (need K%%128==0, Cin%%64==0, ks 1|3, 16-byte pitches, row scales)",
+                     p.K, p.Cin, p.ks, p.ldw, p.ldc);
+    return -1;
+  }
+  if (p.N % 4 != 0 || p.ldo % 4 != 0 || (p.residual && p.ldr % 4 != 0) || (p.rowbias && p.ldrb % 4 != 0)) {
+    af_set_error_msg("conv_gemm fp8: N/ldo/ldr/ldrb must be multiples of 4 (N=%d ldo=%d)", p.N, p.ldo);
+    return -1;
+  }
+  if (p.M <= 0 || p.N <= 0) return 0;
+  {
+    const int HoWo = p.Ho * p.Wo > 0 ? p.Ho * p.Wo : 1;
+    const double nb = (double)((p.M + HoWo - 1) / HoWo);
+    if (nb * (double)p.src_batch_stride >= 4294967280.0 || (double)p.Wrows * p.ldw >= 4294967280.0) {
+      af_set_error_msg("conv_gemm fp8: operand exceeds the 4 GB range of the 32-bit gather offsets (split the batch)");
+      return -1;
+    }
+  }
+  AfGemmPlan pl = plan ? *plan : af_plan_conv_gemm(p, 1, 2);
+  if (pl.tile != 4 && pl.tile != 5) {
+    af_set_error_msg("conv_gemm fp8: shape M=%d N=%d K=%d has no fp8 plan (ask af_plan_conv_gemm first)", p.M, p.N, p.K);
+    return -1;
+  }
+  if (pl.splitk > 1 && !ws) pl.splitk = 1;
+  p.splitk = pl.splitk;
+  p.ws = ws;
+  g_af_last_plan = pl;
+  g_af_plan_counts[10] += 1;
+  if (pl.splitk > 1) g_af_plan_counts[7] += 1;
+  {
+    auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (v > 0 && (1 << s) == v) ? s : -1; };
+    p.howo_shift = lg2(p.Ho * p.Wo);
+    p.wo_shift = lg2(p.Wo);
+  }
+  p.group_m = pl.group_m > 0 ? pl.group_m : 1;
+  p.pp_epilogue = g_af_knobs.pp_direct < 0 ? 0 : (g_af_knobs.pp_direct ? 2 : 1);
+  p.k_tap_inner = 1;
+  AfProfScope prof(AF_K_PP_FP8, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K),
+                   (double)p.M * p.Cin + (double)p.N * p.K + (double)p.M * p.N * 2.0);
+  const int rc = pl.tile == 4 ? launch_pp8<128>(p, stream) : launch_pp8<160>(p, stream);
+  if (rc) return rc;
+  if (p.splitk > 1) {
+    const long nq = (long)p.M * (p.N >> 2);
+    unsigned blocks = (unsigned)((nq + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((splitk_reduce_kernel<bf16>), dim3(blocks), dim3(256), 0, stream, p);
+    HIP_CHECK_RET(hipGetLastError());
+  }
+  return 0;
+}
+
 template <typename T, int TW, int BN> static int launch_halo(const ConvGemmParams& p, hipStream_t stream) {
   using C = HaloCfg<TW, BN>;
   static unsigned long long attr_done = 0;
@@ -1394,6 +1732,10 @@ template <typename T>
 int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t stream, const AfGemmPlan* plan, void* ws) {
   constexpr int BK = 128 / sizeof(T);
   ConvGemmParams p = p_in;
+  if (p.fp8) {
+    if constexpr (sizeof(T) == 2) return batch == 1 ? launch_conv_gemm_fp8(p, stream, plan, ws) : (af_set_error_msg("conv_gemm fp8: no batched form"), -1);
+    else { af_set_error_msg("conv_gemm: fp8 operands need the bf16 storage mode"); return -1; }
+  }
   if (p.K % BK != 0 || p.Cin % BK != 0 || p.K != p.ks * p.ks * p.Cin) {
     af_set_error_msg("conv_gemm: K=%d Cin=%d ks=%d must satisfy K==ks*ks*Cin and Cin%%%d==0", p.K, p.Cin, p.ks, BK);
     return -1;

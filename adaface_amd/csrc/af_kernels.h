@@ -12,7 +12,7 @@ size_t af_gn_workspace_bytes(int B, int HW);
 template <typename T>
 int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn, const float* gamma,
                         const float* beta, float eps, int silu, void* y, long y_bs, int ldy, void* workspace,
-                        hipStream_t stream);
+                        hipStream_t stream, float fp8_mul = 0.f);   // fp8_mul != 0: y is e4m3 bytes of result * fp8_mul
 template <typename T>
 int af_launch_layernorm(const void* x, int ldx, long rows, int Cn, const float* gamma, const float* beta,
                         float eps, void* y, int ldy, hipStream_t stream);
@@ -72,4 +72,8 @@ int af_launch_ln_finalize(const float* part, int parts, int M, int count, float 
 
 // plan of the most recent af_launch_conv_gemm (diagnostics, af_last_gemm_plan)
 extern AfGemmPlan g_af_last_plan;
-extern long g_af_plan_counts[10];
+extern long g_af_plan_counts[11];
+// fp8 (e4m3) twin of a repacked bf16 weight (K in 64-channel units, power-of-two row scales) / saturating bf16 -> e4m3 cast
+int af_launch_quant_weight_fp8(const void* w, int rows, int ldw, int cin_pad, int ks, void* w8, int k8, unsigned char* sc,
+                               hipStream_t stream);
+int af_launch_cast_fp8(const void* x, void* y, long n, float mul, hipStream_t stream);

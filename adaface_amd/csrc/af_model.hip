@@ -72,7 +72,7 @@ static int* knob_slot(const char* name) {
 // ----------------------------------------------------------------------------
 int g_af_prof_enabled = 0;
 int g_af_prof_stride = 1;
-long g_af_prof_seen[AF_K_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+long g_af_prof_seen[AF_K_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 namespace {
 struct ProfRec {
   hipEvent_t start, stop;
@@ -139,6 +139,7 @@ struct Act {  // NHWC activation view
   void* p = nullptr;
   int B = 0, H = 0, W = 0, C = 0;
   int ld = 0;  // elements between pixels
+  bool f8 = false;  // e4m3 bytes (value * 2^AF_FP8_ACT_SHIFT), consumed by an fp8 convolution only
   long npix() const { return (long)B * H * W; }
 };
 
@@ -150,7 +151,13 @@ struct Linear {  // conv or linear weight, repacked [rows_pad][ldw] in storage d
   float* bias = nullptr;
   int cin = 0, cin_pad = 0, cout = 0, ks = 1, rows_pad = 0, ldw = 0;
   bool geglu = false;
+  // fp8 twin (af_set_fp8): e4m3 [rows_pad][k8], K in 64-channel units, one E8M0 scale byte per row
+  void* w8 = nullptr;
+  unsigned char* sc8 = nullptr;
+  int k8 = 0;
 };
+// fp8 activations hold value * 2^3: SiLU(GroupNorm) outputs saturate at +-56 and keep e4m3's 3-bit mantissa down to 2^-9
+constexpr int AF_FP8_ACT_SHIFT = 3;
 struct Norm {
   float* gamma = nullptr;
   float* beta = nullptr;
@@ -265,6 +272,8 @@ struct af_handle {
   size_t ctx_rowmap_n = 0;
 
   bool ln_fold_dirty = true;   // folded LayerNorm twins must be recomputed (a UNet tensor was loaded since)
+  bool fp8_on = false;         // af_set_fp8: ResBlock 3x3 convolutions of the UNet on the block-scaled fp8 MFMA
+  bool fp8_dirty = true;       // fp8 weight twins must be (re)quantised
 
   // diagnostic tap (af_unet_set_tap): block whose output the next forwards also write, fp32 NCHW
   int tap_index = -1;
@@ -731,6 +740,14 @@ struct Runner {
     a.p = A.alloc((size_t)a.npix() * a.ld * esize(dt));
     return a;
   }
+  Act alloc_act8(int B, int H, int W, int C) {   // e4m3 bytes
+    Act a;
+    a.B = B; a.H = H; a.W = W; a.C = C;
+    a.ld = C;
+    a.f8 = true;
+    a.p = A.alloc((size_t)a.npix() * a.ld);
+    return a;
+  }
   int check(const Act& a) {
     if (!a.p) {
       af_set_error_msg("activation arena exhausted (cap %zu)", A.cap);
@@ -776,6 +793,21 @@ struct Runner {
     p.out = out.p; p.ldo = out.ld;
     p.epilogue = L.geglu ? AF_EPI_GEGLU : AF_EPI_NONE;
     p.alpha = 1.0f;
+    if (x.f8) {   // fp8 operands: the twin's K layout and scales (strides of an e4m3 tensor are bytes = elements)
+      p.fp8 = 1;
+      p.W = L.w8; p.ldw = L.k8; p.K = L.k8;
+      p.w_scale = L.sc8;
+      p.x_scale_e8 = 127 - AF_FP8_ACT_SHIFT;
+    }
+  }
+  // would this convolution run on the fp8 ping-pong kernel?  (asked BEFORE its input is produced as e4m3)
+  bool fp8_capable(const Linear& L, const Act& x, const Act& out, int stride = 1, int up = 0) const {
+    if (!h->fp8_on || dt != AF_DTYPE_BF16 || !L.w8 || x.C != L.cin || L.cin != L.cin_pad) return false;
+    Act x8 = x;
+    x8.f8 = true; x8.ld = x.C;
+    ConvGemmParams p;
+    conv_params(p, L, x8, out, stride, up, nullptr, nullptr, 0, -1, -1);
+    return af_plan_conv_gemm(p, 1, 2).tile >= 4;
   }
   // would this 1x1 GEMM run on the ping-pong kernel in one K slice (the only place the LayerNorm epilogues exist)?
   // returns the number of 80-column statistics slabs its output rows would be cut into (0 = no)
@@ -800,7 +832,9 @@ struct Runner {
       af_set_error_msg("conv: input has %d channels (ld %d), layer expects %d (padded %d)", x.C, x.ld, L.cin, L.cin_pad);
       return AF_ERR_INVALID;
     }
+    if (x.f8 && (!L.w8 || ln)) { af_set_error_msg("conv: e4m3 input without an fp8 weight twin"); return AF_ERR_STATE; }
     const AfGemmPlan pl = af_plan_conv_gemm(p, 1, (int)esize(dt));
+    if (x.f8 && pl.tile < 4) { af_set_error_msg("conv: e4m3 input on a shape without an fp8 plan"); return AF_ERR_STATE; }
     void* ws = nullptr;
     if (pl.splitk > 1) {
       const size_t mk = A.mark();
@@ -822,6 +856,9 @@ struct Runner {
     if (!ws) { af_set_error_msg("arena exhausted (groupnorm workspace)"); return AF_ERR_STATE; }
     if (dry) return 0;
     if (x.C != N.C) { af_set_error_msg("groupnorm: C mismatch %d vs %d", x.C, N.C); return AF_ERR_INVALID; }
+    if (y.f8)
+      return af_launch_groupnorm<bf16>(x.p, (long)HW * x.ld, x.ld, x.B, HW, x.C, N.gamma, N.beta, N.eps, silu, y.p,
+                                       (long)HW * y.ld, y.ld, ws, s, (float)(1 << AF_FP8_ACT_SHIFT));
     return DISPATCH(dt,
                     af_launch_groupnorm<bf16>(x.p, (long)HW * x.ld, x.ld, x.B, HW, x.C, N.gamma, N.beta, N.eps, silu,
                                               y.p, (long)HW * y.ld, y.ld, ws, s),
@@ -862,12 +899,13 @@ struct Runner {
 // ResBlock._forward (openaimodel.py:259-279) / ResnetBlock.forward (model.py:122-142)
 static int run_resblock(Runner& R, const ResBlockW& w, const Act& x, Act& out, const void* emb_all, int emb_ld) {
   const size_t mk = R.A.mark();
-  Act t1 = R.alloc_act(x.B, x.H, x.W, x.C);
-  AF_TRY(R.groupnorm(w.n1, x, t1, 1));
+  // (fp8 mode: GroupNorm + SiLU writes e4m3 where the convolution that reads it runs on the fp8 kernel)
   Act t2 = R.alloc_act(x.B, x.H, x.W, w.cout);
+  Act t1 = R.fp8_capable(w.c1, x, t2) ? R.alloc_act8(x.B, x.H, x.W, x.C) : R.alloc_act(x.B, x.H, x.W, x.C);
+  AF_TRY(R.groupnorm(w.n1, x, t1, 1));
   const void* rb = (emb_all && w.emb_off >= 0) ? R.elem_ptr(const_cast<void*>(emb_all), w.emb_off) : nullptr;
   AF_TRY(R.conv(w.c1, t1, t2, 1, 0, nullptr, rb, emb_ld));
-  Act t3 = R.alloc_act(x.B, x.H, x.W, w.cout);
+  Act t3 = R.fp8_capable(w.c2, t2, out) ? R.alloc_act8(x.B, x.H, x.W, w.cout) : R.alloc_act(x.B, x.H, x.W, w.cout);
   AF_TRY(R.groupnorm(w.n2, t2, t3, 1));
   Act sk = x;
   if (w.has_skip) {
@@ -1040,6 +1078,31 @@ static int fold_layernorms(af_handle* h, hipStream_t s) {
                                      t.ff1.rows_pad, C, t.ff1.ldw, s));
     }
   h->ln_fold_dirty = false;
+  return 0;
+}
+
+// fp8 twins of the UNet ResBlock convolutions (allocated on first use, re-quantised after weight loads)
+static int ensure_fp8_twins(af_handle* h, hipStream_t s) {
+  if (!h->fp8_on || !h->fp8_dirty) return 0;
+  if (h->dtype != AF_DTYPE_BF16) { af_set_error_msg("fp8 convolutions need the bf16 storage mode"); return AF_ERR_STATE; }
+  for (auto& r : h->res)
+    for (Linear* L : {&r.c1, &r.c2}) {
+      if (L->cin_pad % 64 != 0 || (L->ks != 1 && L->ks != 3)) continue;
+      if (!L->w8) {
+        const int units = L->ks * L->ks * (L->cin_pad / 64);
+        L->k8 = round_up(units * 64, 128);
+        void* p = nullptr;
+        if (hipMalloc(&p, (size_t)L->rows_pad * L->k8 + L->rows_pad) != hipSuccess) {
+          af_set_error_msg("hipMalloc of an fp8 weight twin failed");
+          return AF_ERR_HIP;
+        }
+        h->owned.push_back(p);
+        L->w8 = p;
+        L->sc8 = reinterpret_cast<unsigned char*>(p) + (size_t)L->rows_pad * L->k8;
+      }
+      AF_TRY(af_launch_quant_weight_fp8(L->w, L->rows_pad, L->ldw, L->cin_pad, L->ks, L->w8, L->k8, L->sc8, s));
+    }
+  h->fp8_dirty = false;
   return 0;
 }
 
@@ -1557,6 +1620,7 @@ static int load_tensor_impl(af_handle* h, const char* name, const float* host_da
   HIP_CHECK_RET(hipStreamSynchronize(0));
   s.loaded = true;
   h->ln_fold_dirty = true;
+  h->fp8_dirty = true;
   return 0;
 }
 
@@ -1688,6 +1752,7 @@ int af_unet_forward(af_handle* h, const float* x_dev, const int64_t* t_dev, floa
   HIP_CHECK_RET(hipSetDevice(h->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   AF_TRY(fold_layernorms(h, s));
+  AF_TRY(ensure_fp8_twins(h, s));
   // size the arena with a dry run
   h->arena.dry = true; h->arena.peak = 0;
   int rc = unet_forward_impl(h, s, x_dev, t_dev, eps_dev, Bf, H, W);
@@ -1866,7 +1931,14 @@ int af_gemm_plan_counts(int64_t* counts10) {
   return AF_OK;
 }
 int af_gemm_plan_counts_reset(void) {
-  for (int i = 0; i < 10; ++i) g_af_plan_counts[i] = 0;
+  for (int i = 0; i < 11; ++i) g_af_plan_counts[i] = 0;
+  return AF_OK;
+}
+int64_t af_fp8_gemm_launches(void) { return g_af_plan_counts[10]; }
+int af_set_fp8(af_handle* h, int on) {
+  if (!h) { af_set_error_msg("af_set_fp8: null handle"); return AF_ERR_INVALID; }
+  if (on && h->dtype != AF_DTYPE_BF16) { af_set_error_msg("af_set_fp8: the fp8 convolutions extend the bf16 mode (handle is f32)"); return AF_ERR_STATE; }
+  h->fp8_on = on != 0;
   return AF_OK;
 }
 int af_prof_collect(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes) {

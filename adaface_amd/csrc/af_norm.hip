@@ -126,6 +126,18 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
+// fp8 output (the consumer is a convolution on the block-scaled fp8 MFMA): OCP e4m3 bytes of value * mul, saturating
+__device__ __forceinline__ unsigned gn_pack4_e4m3(float a, float b, float c, float d, float mul) {
+  a = __builtin_amdgcn_fmed3f(a * mul, -448.f, 448.f);
+  b = __builtin_amdgcn_fmed3f(b * mul, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c * mul, -448.f, 448.f);
+  d = __builtin_amdgcn_fmed3f(d * mul, -448.f, 448.f);
+  int v = 0;
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+  return (unsigned)v;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long batch_stride, int ldc,
                                                         int HW, int Cn, int P,
@@ -134,7 +146,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                                                         const float* __restrict__ beta, int silu,
                                                         T* __restrict__ y, long y_batch_stride, int ldy,
                                                         const float* __restrict__ partial, int nchunk, double count,
-                                                        float eps) {
+                                                        float eps, float fp8_mul) {
   constexpr int EPC = 16 / sizeof(T);
   __shared__ __attribute__((aligned(16))) float s_a[GN_MAX_C];
   __shared__ __attribute__((aligned(16))) float s_b[GN_MAX_C];
@@ -196,13 +208,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
       *reinterpret_cast<float4*>(ca + 4 * q) = *reinterpret_cast<const float4*>(s_a + v * EPC + 4 * q);
       *reinterpret_cast<float4*>(cb + 4 * q) = *reinterpret_cast<const float4*>(s_b + v * EPC + 4 * q);
     }
+    float ff[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float f = fmaf(to_f32<T>(vv.e[e]), ca[e], cb[e]);
       if (silu) f = f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * f));
+      ff[e] = f;
       oo.e[e] = from_f32<T>(f);
     }
-    *reinterpret_cast<uint4*>(yb + (long)pix * ldy + v * EPC) = oo.u;
+    if (fp8_mul != 0.f) {   // (y_batch_stride, ldy in bytes)
+      unsigned char* y8 = reinterpret_cast<unsigned char*>(y) + (long)b * y_batch_stride + (long)pix * ldy + v * EPC;
+#pragma unroll
+      for (int e = 0; e < EPC; e += 4) *reinterpret_cast<unsigned*>(y8 + e) = gn_pack4_e4m3(ff[e], ff[e + 1], ff[e + 2], ff[e + 3], fp8_mul);
+    } else {
+      *reinterpret_cast<uint4*>(yb + (long)pix * ldy + v * EPC) = oo.u;
+    }
     pix += dpix;
     v += dv;
     if (v >= NV) { v -= NV; ++pix; }
@@ -276,7 +296,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x, long batch_stride, int ldc, int HW,
                                                         int Cn, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int silu,
-                                                        T* __restrict__ y, long y_batch_stride, int ldy) {
+                                                        T* __restrict__ y, long y_batch_stride, int ldy, float fp8_mul) {
   constexpr int EPC = 16 / sizeof(T);
   __shared__ float s_ra[4], s_rq[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -320,6 +340,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x, 
       const int pix = it / VP, vv = it - pix * VP;
       const int c0 = g * cpg + vv * EPC;
       Vec16<T> o;
+      float ff[EPC];
 #pragma unroll
       for (int t = 0; t < EPC / 4; ++t) {
         const float4 gm = *reinterpret_cast<const float4*>(gamma + c0 + 4 * t);
@@ -331,10 +352,17 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x, 
           const float sc = gp[e] * rstd;
           float f = fmaf(to_f32<T>(v[i].e[4 * t + e]), sc, bp[e] - mean * sc);
           if (silu) f = f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * f));
+          ff[4 * t + e] = f;
           o.e[4 * t + e] = from_f32<T>(f);
         }
       }
-      *reinterpret_cast<uint4*>(yb + (long)pix * ldy + vv * EPC) = o.u;
+      if (fp8_mul != 0.f) {   // (y_batch_stride, ldy in bytes)
+        unsigned char* y8 = reinterpret_cast<unsigned char*>(y) + (long)b * y_batch_stride + (long)g * cpg + (long)pix * ldy + vv * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) *reinterpret_cast<unsigned*>(y8 + e) = gn_pack4_e4m3(ff[e], ff[e + 1], ff[e + 2], ff[e + 3], fp8_mul);
+      } else {
+        *reinterpret_cast<uint4*>(yb + (long)pix * ldy + vv * EPC) = o.u;
+      }
     }
   }
 }
@@ -425,8 +453,9 @@ size_t af_gn_workspace_bytes(int B, int HW) {
 template <typename T>
 int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn, const float* gamma,
                         const float* beta, float eps, int silu, void* y, long y_bs, int ldy, void* workspace,
-                        hipStream_t stream) {
+                        hipStream_t stream, float fp8_mul) {
   constexpr int EPC = 16 / sizeof(T);
+  if (fp8_mul != 0.f && sizeof(T) != 2) { af_set_error_msg("groupnorm: fp8 output needs the bf16 storage mode"); return -1; }
   if (Cn % GN_GROUPS != 0 || Cn % EPC != 0 || Cn > GN_MAX_C || ldx % EPC != 0 || ldy % EPC != 0) {
     af_set_error_msg("groupnorm: unsupported C=%d (need C%%32==0, C%%%d==0, C<=%d)", Cn, EPC, GN_MAX_C);
     return -1;
@@ -438,7 +467,7 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
     const bool small_ok = g_af_knobs.gn_small != 0;
     if (small_ok && cpg % EPC == 0 && (long)HW * (cpg / EPC) <= 256 * GNS_MAXV && Cn % 4 == 0) {
       hipLaunchKernelGGL((gn_small_kernel<T>), dim3(GN_GROUPS, B), dim3(256), 0, stream, reinterpret_cast<const T*>(x),
-                         x_bs, ldx, HW, Cn, gamma, beta, eps, silu, reinterpret_cast<T*>(y), y_bs, ldy);
+                         x_bs, ldx, HW, Cn, gamma, beta, eps, silu, reinterpret_cast<T*>(y), y_bs, ldy, fp8_mul);
       HIP_CHECK_RET(hipGetLastError());
       return 0;
     }
@@ -455,7 +484,7 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
   if (!fold) hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, partial, nchunk, count, eps, stats);
   hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nchunk, B), dim3(256), 0, stream,
                      reinterpret_cast<const T*>(x), x_bs, ldx, HW, Cn, P, stats, gamma, beta, silu,
-                     reinterpret_cast<T*>(y), y_bs, ldy, fold ? partial : nullptr, nchunk, count, eps);
+                     reinterpret_cast<T*>(y), y_bs, ldy, fold ? partial : nullptr, nchunk, count, eps, fp8_mul);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -488,9 +517,9 @@ int af_launch_layernorm(const void* x, int ldx, long rows, int Cn, const float* 
 }
 
 template int af_launch_groupnorm<bf16>(const void*, long, int, int, int, int, const float*, const float*, float,
-                                       int, void*, long, int, void*, hipStream_t);
+                                       int, void*, long, int, void*, hipStream_t, float);
 template int af_launch_groupnorm<float>(const void*, long, int, int, int, int, const float*, const float*, float,
-                                        int, void*, long, int, void*, hipStream_t);
+                                        int, void*, long, int, void*, hipStream_t, float);
 template int af_launch_layernorm<bf16>(const void*, int, long, int, const float*, const float*, float, void*, int,
                                        hipStream_t);
 template int af_launch_layernorm<float>(const void*, int, long, int, const float*, const float*, float, void*,

@@ -89,6 +89,75 @@ int af_op_conv2d(int dtype, const float* x_dev, const float* w_dev, const float*
   return 0;
 }
 
+// fp8 convolution as the UNet's fp8 mode runs it (bf16 storage): x is cast to bf16, multiplied by 2^act_shift and stored
+// as e4m3 (what the GroupNorm kernels write), the weight is repacked to bf16 and quantised per output row
+// (af_launch_quant_weight_fp8), the ping-pong kernel multiplies on the block-scaled fp8 MFMA; bias / residual / output bf16.
+// Returns AF_ERR_INVALID when the shape has no fp8 plan (the model keeps such layers on bf16).
+int af_op_conv2d_fp8(const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev, float* y_dev,
+                     int B, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int upsample, int act_shift,
+                     void* stream) {
+  if ((ks != 1 && ks != 3) || pad != ks / 2 || Cin % 64 != 0) { af_set_error_msg("af_op_conv2d_fp8: ks 1|3, pad ks/2, Cin%%64==0"); return AF_ERR_INVALID; }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Tmp tmp;
+  const int Hi = H << upsample, Wi = W << upsample;
+  const int Ho = (Hi + 2 * pad - ks) / stride + 1, Wo = (Wi + 2 * pad - ks) / stride + 1;
+  const int co4 = rup(Cout, 4), rows_pad = rup(Cout, 128), ldw = ks * ks * Cin, k8 = rup(ldw, 128);
+  const size_t nx = (size_t)B * H * W * Cin;
+  OP_ALLOC(xn, nx * 2, false);
+  OP_ALLOC(x8, nx, false);
+  OP_ALLOC(wn, (size_t)rows_pad * ldw * 2, true);
+  OP_ALLOC(w8, (size_t)rows_pad * k8 + rows_pad, true);
+  OP_ALLOC(yn, (size_t)B * Ho * Wo * co4 * 2, true);
+  unsigned char* sc = reinterpret_cast<unsigned char*>(w8) + (size_t)rows_pad * k8;
+  void* rn = nullptr;
+  float* bn = nullptr;
+  OP_TRY(af_launch_nchw_to_nhwc<bf16>(x_dev, xn, B, Cin, H * W, Cin, 1.f, s));
+  OP_TRY(af_launch_cast_fp8(xn, x8, (long)nx, (float)(1 << act_shift), s));
+  OP_TRY(af_launch_repack_weight<bf16>(w_dev, wn, Cout, Cin, Cin, ks, ldw, 0, 0, s));
+  OP_TRY(af_launch_quant_weight_fp8(wn, rows_pad, ldw, Cin, ks, w8, k8, sc, s));
+  if (bias_dev) {
+    bn = reinterpret_cast<float*>(tmp.get((size_t)rows_pad * 4, true));
+    if (!bn) return AF_ERR_HIP;
+    if (hipMemcpyAsync(bn, bias_dev, (size_t)Cout * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return AF_ERR_HIP;
+  }
+  if (residual_dev) {
+    rn = tmp.get((size_t)B * Ho * Wo * co4 * 2, false);
+    if (!rn) return AF_ERR_HIP;
+    OP_TRY(af_launch_nchw_to_nhwc<bf16>(residual_dev, rn, B, Cout, Ho * Wo, co4, 1.f, s));
+  }
+  ConvGemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.src = x8; p.src_batch_stride = (long)H * W * Cin; p.ldc = Cin; p.Cin = Cin;
+  p.Hs = H; p.Ws = W; p.up = upsample; p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo;
+  p.ks = ks; p.stride = stride; p.pad = pad;
+  p.W = w8; p.ldw = k8; p.Wrows = rows_pad;
+  p.M = B * Ho * Wo; p.N = co4; p.K = k8;
+  p.bias = bn; p.residual = rn; p.ldr = co4; p.out = yn; p.ldo = co4; p.alpha = 1.f;
+  p.k_logical = ks * ks * Cin;
+  p.fp8 = 1; p.w_scale = sc; p.x_scale_e8 = 127 - act_shift;
+  const AfGemmPlan pl = af_plan_conv_gemm(p, 1, 2);
+  if (pl.tile < 4) { af_set_error_msg("af_op_conv2d_fp8: no fp8 plan for M=%d N=%d K=%d", p.M, p.N, p.K); return AF_ERR_INVALID; }
+  void* ws = nullptr;
+  if (pl.splitk > 1) { ws = tmp.get(pl.ws_bytes, false); if (!ws) return AF_ERR_HIP; }
+  OP_TRY(af_launch_conv_gemm<bf16>(p, 1, s, &pl, ws));
+  OP_TRY(af_launch_nhwc_to_nchw<bf16>(yn, y_dev, B, Cout, Ho * Wo, co4, s));
+  return 0;
+}
+
+// GroupNorm (+SiLU) with the e4m3 output the fp8 convolutions read: y8_dev [B][H*W][C] bytes of result * 2^act_shift
+int af_op_groupnorm_fp8(const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, int silu,
+                        unsigned char* y8_dev, int B, int C, int H, int W, int act_shift, void* stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Tmp tmp;
+  const int HW = H * W;
+  OP_ALLOC(xn, (size_t)B * HW * C * 2, false);
+  OP_ALLOC(ws, af_gn_workspace_bytes(B, HW), false);
+  OP_TRY(af_launch_nchw_to_nhwc<bf16>(x_dev, xn, B, C, HW, C, 1.f, s));
+  OP_TRY(af_launch_groupnorm<bf16>(xn, (long)HW * C, C, B, HW, C, gamma_dev, beta_dev, eps, silu, y8_dev, (long)HW * C, C, ws, s,
+                                   (float)(1 << act_shift)));
+  return 0;
+}
+
 int af_op_linear(int dtype, const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev,
                  float* y_dev, int64_t M, int K, int N, int geglu, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -227,5 +227,10 @@ class Engine:
               "af_clip_text_forward")
         return out
 
+    def set_fp8(self, on: bool = True):
+        """af_set_fp8: the UNet's ResBlock 3x3 convolutions read e4m3 activations / weights (bf16 engines only)."""
+        check(self._lib.af_set_fp8(self._h, 1 if on else 0), "af_set_fp8")
+        self.fp8 = bool(on)
+
     def arena_bytes(self) -> int:
         return int(self._lib.af_arena_bytes(self._h))

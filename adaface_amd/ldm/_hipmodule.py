@@ -47,7 +47,7 @@ class HipModule(nn.Module):
     """nn.Module facade over an Engine.  Subclasses set `_engine_kwargs()` and `_ckpt_prefix`."""
 
     _ckpt_prefix = ""          # prefix the C library expects in front of this module's keys
-    compute_dtype = "bf16"     # "bf16" (throughput) or "f32" (parity mode)
+    compute_dtype = "bf16"     # "bf16" (throughput), "f32" (parity mode) or "fp8" (bf16 + e4m3 ResBlock convolutions)
 
     def __init__(self):
         super().__init__()
@@ -65,8 +65,9 @@ class HipModule(nn.Module):
         return out
 
     def set_compute_dtype(self, dtype: str):
-        """'bf16' or 'f32'; takes effect at the next forward (the engine is rebuilt)."""
-        if dtype not in ("bf16", "f32"):
+        """'bf16', 'f32' or 'fp8' (bf16 storage with the UNet's ResBlock 3x3 convolutions on the block-scaled fp8 MFMA;
+        modules without such layers run it as bf16); takes effect at the next forward (the engine is rebuilt)."""
+        if dtype not in ("bf16", "f32", "fp8"):
             raise ValueError(dtype)
         if dtype != self.compute_dtype:
             self.compute_dtype = dtype
@@ -89,7 +90,11 @@ class HipModule(nn.Module):
         if self._engine is None or self._engine.device.index != idx:
             if self._engine is not None:
                 self._engine.close()
-            object.__setattr__(self, "_engine", Engine(dtype=self.compute_dtype, device=idx, **self._engine_kwargs()))
+            fp8 = self.compute_dtype == "fp8"
+            object.__setattr__(self, "_engine", Engine(dtype="bf16" if fp8 else self.compute_dtype, device=idx,
+                                                       **self._engine_kwargs()))
+            if fp8:
+                self._engine.set_fp8(True)
             self._mark_dirty()
         if self._weights_dirty:
             self.sync_weights()

@@ -228,8 +228,10 @@ class LatentDiffusion(DDPM):
         raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
 
     def set_compute_dtype(self, dtype: str):
+        """'bf16' | 'f32' | 'fp8' (the UNet's ResBlock convolutions in e4m3; VAE and text tower stay bf16)."""
+        rest = "bf16" if dtype == "fp8" else dtype
         self.model.diffusion_model.set_compute_dtype(dtype)
-        self.first_stage_model.set_compute_dtype(dtype)
+        self.first_stage_model.set_compute_dtype(rest)
         if self.cond_stage_model is not None:
-            self.cond_stage_model.set_compute_dtype(dtype)
+            self.cond_stage_model.set_compute_dtype(rest)
         return self

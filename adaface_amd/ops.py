@@ -42,6 +42,40 @@ def conv2d(x, weight, bias=None, stride=1, padding=None, upsample=False, residua
     return y
 
 
+FP8_ACT_SHIFT = 3   # fp8 activations hold value * 2^3 (AF_FP8_ACT_SHIFT in csrc/af_model.hip)
+
+
+def conv2d_fp8(x, weight, bias=None, stride=1, upsample=False, residual=None, act_shift=FP8_ACT_SHIFT):
+    """conv2d with both operands quantised to OCP e4m3 as the UNet's fp8 mode does (x * 2^act_shift saturating, weight
+    rows scaled by a power of two), bf16 bias / residual / output.  Raises AfError when the shape has no fp8 plan."""
+    lib = _lib.load()
+    x, weight = _dev_f32(x), _dev_f32(weight)
+    B, Cin, H, W = x.shape
+    Cout, Cin2, ks, ks2 = weight.shape
+    if Cin2 != Cin or ks != ks2:
+        raise ValueError(f"conv2d_fp8: weight {tuple(weight.shape)} does not match input {tuple(x.shape)}")
+    pad, up = ks // 2, 1 if upsample else 0
+    Hi, Wi = H << up, W << up
+    Ho, Wo = (Hi + 2 * pad - ks) // stride + 1, (Wi + 2 * pad - ks) // stride + 1
+    y = torch.empty(B, Cout, Ho, Wo, device=x.device, dtype=torch.float32)
+    b = None if bias is None else _dev_f32(bias)
+    r = None if residual is None else _dev_f32(residual)
+    check(lib.af_op_conv2d_fp8(ptr(x), ptr(weight), ptr(b), ptr(r), ptr(y), B, Cin, H, W, Cout, ks, stride, pad, up,
+                               act_shift, stream_ptr()), "af_op_conv2d_fp8")
+    return y
+
+
+def group_norm_fp8(x, weight, bias, eps=1e-5, silu=False, act_shift=FP8_ACT_SHIFT):
+    """GroupNorm(32) [+ SiLU] written as e4m3 bytes of result * 2^act_shift: uint8 [B, H*W, C] (NHWC)."""
+    lib = _lib.load()
+    x = _dev_f32(x)
+    B, Cn, H, W = x.shape
+    y = torch.empty(B, H * W, Cn, device=x.device, dtype=torch.uint8)
+    check(lib.af_op_groupnorm_fp8(ptr(x), ptr(_dev_f32(weight)), ptr(_dev_f32(bias)), eps, 1 if silu else 0, ptr(y), B, Cn,
+                                  H, W, act_shift, stream_ptr()), "af_op_groupnorm_fp8")
+    return y
+
+
 def linear(x, weight, bias=None, residual=None, geglu=False, dtype="bf16"):
     """F.linear over the last dim; geglu=True applies GEGLU (attention.py:32-45) to the projection."""
     lib = _lib.load()

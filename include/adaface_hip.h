@@ -152,7 +152,8 @@ int64_t af_arena_bytes(af_handle* h);
 /* ---- per-kernel-class HIP-event timing (bench.py roofline leg) ----
  * classes: 0 conv_gemm (implicit-GEMM conv/linear on the four-wave / halo kernels), 1 attention, 2 groupnorm,
  * 3 layernorm, 4 other, 5 conv_gemm_pp_kernel<160,gather> (3x3 / strided convs on the eight-wave ping-pong kernel),
- * 6 conv_gemm_pp_kernel<160,plain> (1x1 convs / linears), 7 conv_gemm_pp_kernel<128,*> (GEGLU, VAE widths).
+ * 6 conv_gemm_pp_kernel<160,plain> (1x1 convs / linears), 7 conv_gemm_pp_kernel<128,*> (GEGLU, VAE widths),
+ * 8 conv_gemm_pp_kernel<*,*,0,true> (fp8 operands, af_set_fp8).
  * While enabled every launch of a class is bracketed by hipEventRecord on ITS stream; af_prof_collect
  * sums elapsed ms, launch counts and the ALGORITHMIC flops / bytes of those launches per class. */
 int af_prof_enable(int class_mask); /* bit c set = time class c; 0 = off */
@@ -197,6 +198,18 @@ int af_op_linear(int dtype, const float* x_dev, const float* w_dev, const float*
 /* F.group_norm(x, 32, gamma, beta, eps) on NCHW, optional SiLU. */
 int af_op_groupnorm(int dtype, const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, int silu,
                     float* y_dev, int B, int C, int H, int W, void* stream);
+/* fp8 (OCP e4m3) operand variant of the UNet's ResBlock convolutions (BASELINE config 4: "fp8 MFMA QKV/conv"; the
+ * reference has no fp8 path: torch autocast fp16 at most, scripts/stable_txt2img.py:711).  af_set_fp8(h, 1) on a bf16
+ * handle: GroupNorm + SiLU (openaimodel.py:259-263, in_layers / out_layers) writes e4m3 and the 3x3 convolutions that read
+ * it multiply on v_mfma_scale_f32_16x16x128_f8f6f4 with power-of-two scales (per output channel for the weights, 2^3 for
+ * the activations); everything else stays bf16.  Tolerance: tests/test_fp8_gpu.py. */
+int af_set_fp8(af_handle* h, int on);
+int64_t af_fp8_gemm_launches(void); /* launches on the fp8 kernel since af_gemm_plan_counts_reset */
+int af_op_conv2d_fp8(const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev, float* y_dev,
+                     int B, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int upsample, int act_shift,
+                     void* stream);
+int af_op_groupnorm_fp8(const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, int silu,
+                        unsigned char* y8_dev, int B, int C, int H, int W, int act_shift, void* stream);
 /* F.layer_norm over the last dim of [rows, C]. */
 int af_op_layernorm(int dtype, const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps,
                     float* y_dev, int64_t rows, int C, void* stream);

@@ -2,7 +2,8 @@
 """Per-shape kernel microbenchmark at the SD-1.5 / Bf=16 shapes (kernel-only time from the library's HIP-event
 profiler, so the layout conversions of the op-level API are excluded).  Prints TFLOP/s or GB/s per shape.
 
-    python scripts/bench_shapes.py [--dtype bf16] [--reps 5] [--only conv|linear|attn|norm]
+    python scripts/bench_shapes.py [--dtype bf16] [--reps 5] [--only conv|linear|attn|norm|conv8]
+    (conv8: the ResBlock convolutions with e4m3 operands next to their bf16 form, same process)
 """
 import argparse
 import ctypes as C
@@ -38,7 +39,7 @@ def timed(cls, fn):
         fn()
     torch.cuda.synchronize()
     lib.af_prof_enable(0)
-    n = 8
+    n = 9
     ms = (C.c_double * n)(); la = (C.c_int64 * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)()
     lib.af_prof_collect(n, ms, la, fl, by)
     tms, tla = sum(ms[c] for c in classes), sum(la[c] for c in classes)
@@ -71,6 +72,20 @@ if args.only in ("", "conv"):
         show(f"conv{ks}x{ks} {cin}->{cout}@{H} s{st} up{up} B{b} (x{cnt})", ms, fl, by)
         tot += ms * cnt
     print(f"  conv weighted total per forward: {tot:.2f} ms")
+
+if args.only == "conv8":
+    convs = [(320, 320, 64, 13), (640, 320, 64, 2), (960, 320, 64, 1), (320, 640, 32, 1), (640, 640, 32, 11), (1280, 640, 32, 1),
+             (1920, 640, 32, 1), (640, 1280, 16, 1), (1280, 1280, 16, 11), (2560, 1280, 16, 2), (1280, 1280, 8, 12), (2560, 1280, 8, 3)]
+    tot = tot8 = 0.0
+    for cin, cout, H, cnt in convs:
+        x = torch.nn.functional.silu(rn(Bf, cin, H, H)); w = rn(cout, cin, 3, 3) * (cin * 9) ** -0.5; bias = rn(cout)
+        ms, fl, by = timed(0, lambda: ops.conv2d(x, w, bias, dtype="bf16"))
+        ms8, fl8, by8 = timed(8, lambda: ops.conv2d_fp8(x, w, bias))
+        show(f"conv3x3 {cin}->{cout}@{H} B{Bf} bf16 (x{cnt})", ms, fl, by)
+        show(f"conv3x3 {cin}->{cout}@{H} B{Bf} e4m3 (x{cnt})  [{ms / ms8:.2f}x]", ms8, fl8, by8)
+        tot += ms * cnt
+        tot8 += ms8 * cnt
+    print(f"  ResBlock conv weighted total per forward: bf16 {tot:.2f} ms, e4m3 {tot8:.2f} ms")
 
 if args.only in ("", "linear"):
     lins = [  # M, K, N, geglu, count

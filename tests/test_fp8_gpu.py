@@ -1,0 +1,156 @@
+"""fp8 (OCP e4m3) operand variant of the UNet's ResBlock convolutions (BASELINE.json config 4: "fp8 MFMA QKV/conv").
+
+The reference has no fp8 path, so there is nothing of its own to compare an fp8 result with; what is pinned is
+  (1) the KERNEL: af_op_conv2d_fp8 against a torch convolution of the SAME quantised operands (x * 2^3 -> e4m3, weight rows
+      * 2^e -> e4m3, torch.float8_e4m3fn emulation) — quantisation is exact to emulate, so the bar is the bf16-output bar
+      (5e-3 of the output scale), over 3x3 / 1x1 / strided / upsampled / split-K shapes and channel counts that are
+      multiples of 64 but not of 128 (a K tile straddling two filter taps);
+  (2) the PRODUCER: GroupNorm + SiLU written as e4m3 within half an e4m3 step of the f32 result;
+  (3) the MODEL: full SD-1.5 UNet at the benchmark batch in fp8 mode against its own bf16 and f32-mode forwards.  Stated
+      tolerance of the fp8 mode: max-abs eps deviation <= 8e-2 of max|eps| per forward against f32 (measured: see
+      gpurun_out/parity_report.txt); the bf16 mode's bar is 3e-2.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ACT_SHIFT = 3
+FP8_FORWARD_TOL = 8e-2
+
+
+def _e4m3(t):
+    return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+
+
+def _quant_x(x):
+    return _e4m3(x.to(torch.bfloat16).float() * 2.0 ** ACT_SHIFT) / 2.0 ** ACT_SHIFT
+
+
+def _quant_w(w):
+    wb = w.to(torch.bfloat16).float()
+    mx = wb.flatten(1).abs().amax(dim=1).clamp_min(1e-30)
+    e = torch.floor(torch.log2(448.0 / mx))
+    # floor(log2()) can be off by one at exact powers of two: enforce the definition (largest e with mx * 2^e <= 448)
+    e = torch.where(mx * 2.0 ** (e + 1) <= 448.0, e + 1, e)
+    e = torch.where(mx * 2.0 ** e > 448.0, e - 1, e)
+    s = (2.0 ** e).view(-1, 1, 1, 1)
+    return _e4m3(wb * s) / s
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,ks,stride,up,bias,res", [
+    (2, 320, 64, 64, 320, 3, 1, False, True, True),      # the dominant ResBlock conv: 45 units = 22.5 tiles (zero half tile)
+    (2, 640, 64, 64, 320, 3, 1, False, True, False),     # decoder ResBlock in_layers conv
+    (1, 960, 64, 64, 320, 3, 1, False, True, False),     # 15 chunks x 9 taps: odd unit count, tiles straddle taps
+    (4, 640, 32, 32, 640, 3, 1, False, True, True),
+    (16, 1280, 8, 8, 1280, 3, 1, False, True, True),     # M = 1024: sliced K + reduce
+    (8, 1280, 16, 16, 1280, 3, 1, False, False, False),
+    (4, 320, 32, 32, 640, 1, 1, False, True, False),     # 1x1: plain (no gather) variant, 5 units
+    (2, 128, 32, 32, 256, 3, 1, False, True, False),     # N % 128 only -> 256x128 tile
+    (2, 64, 32, 32, 160, 3, 2, False, True, False),      # stride 2, one unit per tap
+    (2, 128, 16, 16, 320, 3, 1, True, False, True),      # nearest-2x upsample folded into the gather
+    (3, 192, 24, 24, 160, 3, 1, False, True, False),     # M = 1728: ragged last M tile, Ho*Wo not a power of two
+])
+def test_conv2d_fp8_kernel(gpu, report, knobs, B, Cin, H, W, Cout, ks, stride, up, bias, res):
+    from adaface_amd import _lib, ops
+    knobs("gemm_pp_minfill", 0)
+    g = torch.Generator().manual_seed(Cin + Cout + H + ks + 7)
+    x = F.silu(torch.randn(B, Cin, H, W, generator=g) * 1.5)              # the range the producer emits
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    w = w * (0.25 + 4.0 * torch.rand(Cout, 1, 1, 1, generator=g))         # rows of different magnitude: per-row scales
+    b = torch.randn(Cout, generator=g) * 0.1 if bias else None
+    xq, wq = _quant_x(x), _quant_w(w)
+    xi = F.interpolate(xq, scale_factor=2.0, mode="nearest") if up else xq
+    ref = F.conv2d(xi.double(), wq.double(), None if b is None else b.double(), stride=stride, padding=ks // 2).float()
+    r = torch.randn(ref.shape, generator=g).to(torch.bfloat16).float() if res else None
+    if res:
+        ref = ref + r
+    _lib.plan_counts(reset=True)
+    got = ops.conv2d_fp8(x.to(gpu), w.to(gpu), None if b is None else b.to(gpu), stride=stride, upsample=up,
+                         residual=None if r is None else r.to(gpu)).cpu()
+    pc = _lib.plan_counts(reset=True)
+    assert pc["fp8"] == 1, pc
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    report(f"fp8 conv{ks}x{ks} {Cin}->{Cout}@{H}x{W} B{B} s{stride} up{int(up)} vs same-operand reference", err, scale, 5e-3 * scale)
+    assert torch.isfinite(got).all() and err <= 5e-3 * scale, (err, scale)
+    # and how far the quantisation itself moves the result (reported, not asserted: this IS the fp8 error)
+    xb, wb = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
+    xbi = F.interpolate(xb, scale_factor=2.0, mode="nearest") if up else xb
+    full = F.conv2d(xbi, wb, b, stride=stride, padding=ks // 2) + (r if res else 0)
+    report(f"fp8 conv{ks}x{ks} {Cin}->{Cout}@{H}x{W} quantisation error (vs bf16 operands)", (got - full).abs().max().item(), scale)
+
+
+def test_conv2d_fp8_refuses_unplannable_shape(gpu):
+    from adaface_amd import _lib, ops
+    x = torch.randn(1, 64, 8, 8)
+    w = torch.randn(100, 64, 3, 3)          # N = 100: neither 160 nor 128 columns
+    with pytest.raises(_lib.AfError):
+        ops.conv2d_fp8(x.to(gpu), w.to(gpu))
+
+
+@pytest.mark.parametrize("B,C,H,W,silu", [(2, 320, 64, 64, True), (2, 1280, 8, 8, True), (1, 640, 32, 32, False),
+                                          (1, 2560, 16, 16, True)])
+def test_groupnorm_fp8_output(gpu, report, B, C, H, W, silu):
+    """Both GroupNorm kernels (chunked apply / small-map single launch) with the e4m3 output: every byte decodes to within
+    half an e4m3 step (2^-4 relative, 2^-10 / 8 absolute in the subnormal range) of the f32 result, saturating at 448 / 8."""
+    from adaface_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.7 + 0.4).to(torch.bfloat16).float()
+    w = torch.randn(C, generator=g) * 0.3 + 1.0
+    b = torch.randn(C, generator=g) * 0.2
+    ref = F.group_norm(x, 32, w, b, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    y8 = ops.group_norm_fp8(x.to(gpu), w.to(gpu), b.to(gpu), eps=1e-5, silu=silu).cpu()
+    got = y8.view(torch.float8_e4m3fn).float().view(B, H * W, C).permute(0, 2, 1).reshape(B, C, H, W) / 2.0 ** ACT_SHIFT
+    assert torch.isfinite(got).all()
+    refc = ref.clamp(-448.0 / 8, 448.0 / 8)
+    bound = refc.abs() * (2.0 ** -4) * 1.02 + 2.0 ** -10 / 8 + 2e-4     # half step (+ the kernels' f32 rounding)
+    excess = ((got - refc).abs() - bound).max().item()
+    report(f"groupnorm->e4m3 C{C} {H}x{W}: worst excess over half an e4m3 step", max(excess, 0.0), 1.0, 0.0)
+    assert excess <= 0.0, excess
+
+
+def test_sd15_unet_fp8_mode(gpu, report):
+    """Full SD-1.5 UNet at the benchmark batch (Bf = 16): fp8 mode against the bf16 and f32-mode forwards of the same
+    weights and inputs; asserts that the ResBlock convolutions really ran on the fp8 kernel (44 launches: 22 ResBlocks)."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from oracle import ldm_oracle as O
+    from adaface_amd import _lib
+    from adaface_amd.engine import Engine
+    from adaface_amd.synth import synth_weights_into
+    from tests.test_model_gpu import _unet_kwargs
+    cfg = O.SD15_UNET
+    g = torch.Generator().manual_seed(52)
+    x = torch.randn(16, 4, 64, 64, generator=g).to(gpu)
+    t = torch.full((16,), 501, dtype=torch.long, device=gpu)
+    ctx = torch.randn(16 * 16, 77, cfg.context_dim, generator=g).to(gpu)
+    eps = {}
+    for mode in ("f32", "bf16"):
+        eng = Engine(dtype=mode, unet=_unet_kwargs(cfg))
+        synth_weights_into(eng, O.unet_param_shapes(cfg), seed=51, device=gpu)
+        eng.set_context(ctx, 16, layerwise=True)
+        eps[mode] = eng.unet_forward(x, t)
+        if mode == "bf16":
+            eng.set_fp8(True)
+            _lib.plan_counts(reset=True)
+            eps["fp8"] = eng.unet_forward(x, t)
+            pc = _lib.plan_counts(reset=True)
+            assert pc["fp8"] == 44, pc
+            eng.set_fp8(False)
+            again = eng.unet_forward(x, t)
+            assert _lib.plan_counts(reset=True)["fp8"] == 0 and torch.equal(again, eps["bf16"])   # the switch is clean
+        eng.close()
+    scale = eps["f32"].abs().max().item()
+    e_bf = (eps["bf16"] - eps["f32"]).abs().max().item() / scale
+    e_f8 = (eps["fp8"] - eps["f32"]).abs().max().item() / scale
+    rms = ((eps["fp8"] - eps["f32"]).pow(2).mean().sqrt() / eps["f32"].pow(2).mean().sqrt()).item()
+    report("sd15_unet Bf=16 bf16 forward vs f32-mode forward", e_bf, scale, 3e-2)
+    report("sd15_unet Bf=16 fp8-conv forward vs f32-mode forward (max-abs / max|eps|)", e_f8, scale, FP8_FORWARD_TOL)
+    report("sd15_unet Bf=16 fp8-conv forward vs f32-mode forward (rms / rms)", rms, 1.0)
+    assert torch.isfinite(eps["fp8"]).all() and e_f8 <= FP8_FORWARD_TOL, (e_f8, e_bf)
