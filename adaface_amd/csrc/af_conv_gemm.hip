@@ -453,6 +453,9 @@ template <int BN> struct PpCfg {
   static constexpr int NI = HN / 16, MI = 4;        // 16x16 blocks per wave
   static constexpr int XBYTES = BM * 128, WBYTES = BN * 128, SLOT = XBYTES + WBYTES;
   static constexpr int XP = BM / 8, WP = BN / 8;    // 1-KiB pieces per K tile
+  // (splitting the gathers evenly between the two groups -- 4 + 2..3 pieces per wave each -- measured 5 % SLOWER on the
+  // bf16 3x3 convolutions and the same on fp8: the group that computes first after a barrier is better left with the
+  // cheap weight pieces)
   static constexpr int XP0 = ((XP + WP + 7) / 8) * 4;  // activation pieces staged by group 0
   static constexpr int NP0 = XP0 / 4;               // pieces per wave, group 0 (all activation)
   static constexpr int NX1 = (XP - XP0) / 4;        // activation pieces per wave, group 1
@@ -504,8 +507,9 @@ typedef __attribute__((ext_vector_type(4))) int pp_i32x4;
 // the bf16 kernel already uses.  A K tile is two 64-channel UNITS (unit u = channel chunk u / taps, tap u % taps), so
 // that channel counts that are multiples of 64 but not of 128 (320, 960) waste nothing: chunks 0-3 of an LDS row come
 // from unit 2t, chunks 4-7 from unit 2t + 1, each lane of the staging waves walks the units of ITS half.
-template <int BN, bool GATHER, int LNMODE = 0, bool FP8 = false>
+template <int BN, bool GATHER, int LNMODE = 0, bool FP8 = false, bool NS = FP8>
 __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams p) {
+  static_assert(NS || !FP8, "fp8 operands exist on the block-ordered schedule only");
   using C = PpCfg<BN>;
   typedef bf16 T;
   static_assert(!FP8 || LNMODE == 0, "fp8 operands: plain epilogue only");
@@ -541,8 +545,9 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
   const unsigned lchunk = (FP8 ? (dchunk & 3u) : dchunk) * 16u;     // ... its byte offset inside the 64-channel run
   const int HoWo = p.Ho * p.Wo;
   const unsigned ldcb = (unsigned)p.ldc * XE;
+  const bool fast_taps = GATHER && p.up == 0 && p.ks * p.ks <= 31 && p.fast_taps;
   unsigned x_off[NP0];
-  int x_yx[GATHER ? NP0 : 1];   // (iy0 << 16) | (ix0 & 0xffff): input coordinate of tap (0,0)
+  int x_yx[GATHER ? NP0 : 1];   // (iy0 << 16) | (ix0 & 0xffff): input coordinate of tap (0,0); fast taps: validity mask
   pp_static_for<0, NP0>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
     const int piece = g == 0 ? wq + 4 * q : XP0 + wq + 4 * q;
@@ -565,7 +570,23 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     }
     unsigned off = (unsigned)((long)b * p.src_batch_stride * XE) + lchunk;
     if constexpr (GATHER) {
-      x_yx[q] = ok ? (((oy * p.stride - p.pad) << 16) | ((ox * p.stride - p.pad) & 0xffff)) : (int)0xC0000000;
+      const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;
+      if (fast_taps) {
+        // no upsample: the address of tap (ky, kx) is the tap-(0,0) address plus a wave-uniform delta, and whether the tap
+        // falls inside the image is one bit of a mask made here (row bits x column bits) -- the staging phase then spends
+        // 4 vector instructions per piece instead of 12, issue slots it competes for with the partner wave's MFMAs
+        int vy = 0, vx = 0;
+        for (int k = 0; k < p.ks; ++k) {
+          vy |= ((unsigned)(y0 + k) < (unsigned)p.Hi ? 1 : 0) << (k * p.ks);
+          vx |= ((unsigned)(x0 + k) < (unsigned)p.Wi ? 1 : 0) << k;
+        }
+        int msk = 0;
+        for (int k = 0; k < p.ks; ++k) msk |= ((vy >> (k * p.ks)) & 1) ? (vx << (k * p.ks)) : 0;
+        x_yx[q] = ok ? msk : 0;
+        off += (unsigned)(y0 * p.Ws + x0) * ldcb;     // (wraps for border pixels; only in-image taps are fetched)
+      } else {
+        x_yx[q] = ok ? ((y0 << 16) | (x0 & 0xffff)) : (int)0xC0000000;
+      }
     } else {
       off += (unsigned)(((oy * p.stride) >> p.up) * p.Ws + ((ox * p.stride) >> p.up)) * ldcb;
       if (!ok) off = 0xFFFFFFFFu;
@@ -606,10 +627,16 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     u_tap = u - cc * taps8;
     u_c0 = cc * 64;
   }
-  auto x_addr = [&](auto qc) -> unsigned {
+  int s_tapbit = 0;          // bf16 fast taps: bit of the tap being staged, byte delta of its pixel
+  unsigned s_delta = 0u;
+  int u_ok = 0;              // fp8 fast taps (per lane): unit inside K, byte delta of its tap + channel offset
+  unsigned u_delta = 0u;
+  auto x_addr = [&](auto qc, auto ftc) -> unsigned {
     constexpr int q = decltype(qc)::value;
+    constexpr bool FT = decltype(ftc)::value;   // fast taps (compile-time here: one uniform branch per stage() call, not per piece)
     if constexpr (FP8) {
       if constexpr (GATHER) {
+        if constexpr (FT) return ((x_yx[q] >> u_tap) & u_ok) ? x_off[q] + u_delta : 0xFFFFFFFFu;
         const int kyl = p.ks == 3 ? (u_tap * 11) >> 5 : 0, kxl = p.ks == 3 ? u_tap - 3 * kyl : 0;
         const int iy = (x_yx[q] >> 16) + kyl, ix = ((x_yx[q] << 16) >> 16) + kxl;
         const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && u_c0 < p.Cin;
@@ -619,6 +646,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
         return (u_c0 < p.Cin && x_off[q] != 0xFFFFFFFFu) ? x_off[q] + (unsigned)u_c0 : 0xFFFFFFFFu;
       }
     } else if constexpr (GATHER) {
+      if constexpr (FT) return (x_yx[q] & s_tapbit) ? x_off[q] + s_delta : 0xFFFFFFFFu;
       const int iy = (x_yx[q] >> 16) + ky, ix = ((x_yx[q] << 16) >> 16) + kx;
       const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
       const unsigned pix = (unsigned)((iy >> p.up) * p.Ws + (ix >> p.up));
@@ -628,18 +656,35 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     }
   };
   auto stage = [&](int slot_off) {
+    if (fast_taps) {
+      if constexpr (FP8) {
+        const int kyl = p.ks == 3 ? (u_tap * 11) >> 5 : 0, kxl = p.ks == 3 ? u_tap - 3 * kyl : 0;
+        u_ok = u_c0 < p.Cin ? 1 : 0;
+        u_delta = (unsigned)(kyl * p.Ws + kxl) * ldcb + (unsigned)u_c0;
+      } else {
+        s_tapbit = 1 << (ky * p.ks + kx);
+        s_delta = (unsigned)(ky * p.Ws + kx) * ldcb;
+      }
+    }
     const unsigned c0b = FP8 ? 0u : (unsigned)c0 * 2u;
     const unsigned k0b = (!FP8 && p.k_tap_inner) ? (unsigned)((ky * p.ks + kx) * p.Cin + c0) * 2u : (unsigned)ktile * 128u;
     char* base = smem + slot_off;
-    pp_static_for<0, NPMAX>([&](auto qc) {
-      constexpr int q = decltype(qc)::value;
-      if (g == 0) {
-        if constexpr (q < NP0) lds_dma16(rs_x, base + (wq + 4 * q) * 1024, x_addr(qc), c0b);
-      } else {
-        if constexpr (q < NX1) lds_dma16(rs_x, base + (XP0 + wq + 4 * q) * 1024, x_addr(qc), c0b);
-        else if constexpr (q < NP1) lds_dma16(rs_w, base + XBYTES + (wq + 4 * (q - NX1)) * 1024, w_off[q - NX1], k0b);
-      }
-    });
+    auto issue = [&](auto ftc) {
+      pp_static_for<0, NPMAX>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if (g == 0) {
+          if constexpr (q < NP0) lds_dma16(rs_x, base + (wq + 4 * q) * 1024, x_addr(qc, ftc), c0b);
+        } else {
+          if constexpr (q < NX1) lds_dma16(rs_x, base + (XP0 + wq + 4 * q) * 1024, x_addr(qc, ftc), c0b);
+          else if constexpr (q < NP1) lds_dma16(rs_w, base + XBYTES + (wq + 4 * (q - NX1)) * 1024, w_off[q - NX1], k0b);
+        }
+      });
+    };
+    if constexpr (GATHER) {
+      if (fast_taps) issue(std::true_type{}); else issue(std::false_type{});
+    } else {
+      issue(std::false_type{});
+    }
     ++ktile;
     if constexpr (FP8) {
       u_tap += adv_r;
@@ -706,7 +751,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
       if (p.bias && p.splitk <= 1) bias_r[i] = *reinterpret_cast<const float4*>(p.bias + n0 + g * C::HN + i * 16 + cl);
     }
   };
-  if constexpr (!FP8) load_bias();   // (FP8: 104 fragment registers in the loop; the bias is fetched after it)
+  if constexpr (!NS) load_bias();   // (block-ordered schedule: 104 fragment registers in the loop; the bias is fetched after it)
 
   // LayerNorm consumer: column sums of W * gamma for this lane's channels and mu / rstd of its four rows
   float4 ln_cs[LNMODE == 1 ? NI : 1];
@@ -731,9 +776,15 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
   // those are double-buffered (xa8 / xb8 alternate per tile).  Reads are issued in the order W0 X0 X1 X2 X3 W1 .. W(NI-1):
   // two blocks up front, then one block (two ds_read_b128) behind each MFMA; every MFMA waits with a counted lgkmcnt for
   // exactly the blocks it needs (LDS reads return in order).
-  pp_u32x4 w8[FP8 ? NI : 1][2], xa8[FP8 ? MI : 1][2], xb8[FP8 ? MI : 1][2];
+  pp_u32x4 w8[NS ? NI : 1][2], xa8[NS ? MI : 1][2], xb8[NS ? MI : 1][2];
   int wsc8[FP8 ? NI : 1];
   int xsc8 = p.x_scale_e8;
+  if constexpr (NS && !FP8) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) w8[i][0] = w8[i][1] = pp_u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < MI; ++j) xa8[j][0] = xa8[j][1] = xb8[j][0] = xb8[j][1] = pp_u32x4{0u, 0u, 0u, 0u};
+  }
   if constexpr (FP8) {
     // the activation scale as a VGPR made HERE: first used inside the loop, the kernel-argument load behind it would get
     // its s_waitcnt lgkmcnt(0) in front of the first MFMA of every other tile, draining the fragment reads just issued
@@ -747,6 +798,12 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     for (int j = 0; j < MI; ++j) xa8[j][0] = xa8[j][1] = xb8[j][0] = xb8[j][1] = pp_u32x4{0u, 0u, 0u, 0u};
   }
   auto mfma8 = [&](f32x4& c, const pp_u32x4 (&wv)[2], const pp_u32x4 (&xv)[2], int wscale) {
+    if constexpr (!FP8) {   // bf16: the two K halves of the 64-value tile (chunks q and q + 4)
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[0]), __builtin_bit_cast(bf16x8, xv[0]), c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[1]), __builtin_bit_cast(bf16x8, xv[1]), c, 0, 0, 0);
+      asm volatile("" : "+v"(c));
+      return;
+    }
     const pp_i32x8 a = __builtin_shufflevector(__builtin_bit_cast(pp_i32x4, wv[0]), __builtin_bit_cast(pp_i32x4, wv[1]), 0, 1, 2, 3, 4, 5, 6, 7);
     const pp_i32x8 b = __builtin_shufflevector(__builtin_bit_cast(pp_i32x4, xv[0]), __builtin_bit_cast(pp_i32x4, xv[1]), 0, 1, 2, 3, 4, 5, 6, 7);
     c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, wscale, 0, xsc8);
@@ -757,8 +814,8 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     constexpr int n = decltype(nc)::value;
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(blk[0]), "+v"(blk[1]) : "n"(n) : "memory");
   };
-  auto cphase8 = [&](int slot_off, pp_u32x4 (&xc)[FP8 ? MI : 1][2], pp_u32x4 (&xp)[FP8 ? MI : 1][2]) {
-    if constexpr (FP8) {
+  auto cphase8 = [&](int slot_off, pp_u32x4 (&xc)[NS ? MI : 1][2], pp_u32x4 (&xp)[NS ? MI : 1][2]) {
+    if constexpr (NS) {
       constexpr int NB = NI + MI;
       const unsigned b0 = lds0 + (unsigned)slot_off + fch0, b1 = lds0 + (unsigned)slot_off + fch1;
       auto rd_block = [&](auto bc) {
@@ -780,7 +837,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
       pp_static_for<0, MI * NI>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         if constexpr (m < MI) {
-          mfma8(acc[NI - 1][m], w8[NI - 1], xp[m], wsc8[NI - 1]);          // held back from the previous tile
+          mfma8(acc[NI - 1][m], w8[NI - 1], xp[m], wsc8[FP8 ? NI - 1 : 0]);   // held back from the previous tile
         } else {
           constexpr int i = (m - MI) / MI, j = (m - MI) % MI;
           constexpr int issued = (2 + m) < NB ? (2 + m) : NB;               // blocks issued before this MFMA
@@ -790,7 +847,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
             if constexpr (i == 0) wait_block(cnt, xc[j]); else wait_block(cnt, w8[i]);
             if constexpr (i == 0 && j == 0) wait_block(cnt, w8[0]);
           }
-          mfma8(acc[i][j], w8[i], xc[j], wsc8[i]);
+          mfma8(acc[i][j], w8[i], xc[j], wsc8[FP8 ? i : 0]);
         }
         if constexpr (2 + m < NB) rd_block(std::integral_constant<int, 2 + m>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -807,12 +864,15 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
   __builtin_amdgcn_s_barrier();
   if (g == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one interval behind
   int rd = 0, w0 = SLOT, w1 = 2 * SLOT;       // slots of tiles t, t+1, t+2
+  // (experiment, pp_prio knob: 0 = compute phase at priority 1 (shipped), 1 = no priorities, 2 = staging phase at priority 1)
   auto dphase = [&](int t) {
+    if (p.pp_prio == 2) __builtin_amdgcn_s_setprio(1);
     if (g == 0) {
       if (t + 1 < KT) { stage(w0); wait_keep1(); } else pp_wait_vm<0>();   // own part of tile t landed
     } else {
       if (t + 2 < KT) stage(w1);
     }
+    if (p.pp_prio == 2) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_s_barrier();
   };
   auto cend = [&](int t) {
@@ -820,28 +880,28 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     __builtin_amdgcn_s_barrier();
     const int tmp = rd; rd = w0; w0 = w1; w1 = tmp;
   };
-  if constexpr (FP8) {
+  if constexpr (NS) {
     for (int t = 0; t < KT; t += 2) {
       dphase(t);
-      __builtin_amdgcn_s_setprio(1);
+      if (p.pp_prio == 0) __builtin_amdgcn_s_setprio(1);
       cphase8(rd, xa8, xb8);
-      __builtin_amdgcn_s_setprio(0);
+      if (p.pp_prio == 0) __builtin_amdgcn_s_setprio(0);
       cend(t);
       if (t + 1 < KT) {
         dphase(t + 1);
-        __builtin_amdgcn_s_setprio(1);
+        if (p.pp_prio == 0) __builtin_amdgcn_s_setprio(1);
         cphase8(rd, xb8, xa8);
-        __builtin_amdgcn_s_setprio(0);
+        if (p.pp_prio == 0) __builtin_amdgcn_s_setprio(0);
         cend(t + 1);
       }
     }
     // the last tile's held-back MFMAs
     if (KT & 1) {
 #pragma unroll
-      for (int j = 0; j < MI; ++j) mfma8(acc[NI - 1][j], w8[NI - 1], xa8[j], wsc8[NI - 1]);
+      for (int j = 0; j < MI; ++j) mfma8(acc[NI - 1][j], w8[NI - 1], xa8[j], wsc8[FP8 ? NI - 1 : 0]);
     } else {
 #pragma unroll
-      for (int j = 0; j < MI; ++j) mfma8(acc[NI - 1][j], w8[NI - 1], xb8[j], wsc8[NI - 1]);
+      for (int j = 0; j < MI; ++j) mfma8(acc[NI - 1][j], w8[NI - 1], xb8[j], wsc8[FP8 ? NI - 1 : 0]);
     }
   } else {
     for (int t = 0; t < KT; ++t) {
@@ -865,7 +925,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
                                                             __builtin_bit_cast(bf16x8, xf[j][1]), acc[i][j], 0, 0, 0);
   }
   if (g == 0) __builtin_amdgcn_s_barrier();
-  if constexpr (FP8) load_bias();
+  if constexpr (NS) load_bias();
 
   // ------------------------------- epilogue -------------------------------
   // GEGLU is evaluated in registers by all eight waves first (value block 2k, gate block 2k+1 of the same lane);
@@ -1628,14 +1688,17 @@ static int launch_cfg(const ConvGemmParams& p, int batch, hipStream_t stream) {
   return use_dma ? launch_cfg2<T, BM, BN, true>(p, batch, stream) : launch_cfg2<T, BM, BN, false>(p, batch, stream);
 }
 
-template <int BN> static int launch_pp(const ConvGemmParams& p, hipStream_t stream) {
+template <int BN, int LNMODE, bool GATHER, bool NS> static int launch_pp_one(const ConvGemmParams& p, dim3 grid, hipStream_t stream) {
   using C = PpCfg<BN>;
+  static unsigned long long attr_done = 0;
+  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, GATHER, LNMODE, false, NS>), C::LDS_BYTES)) return rc;
+  hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, GATHER, LNMODE, false, NS>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <int BN> static int launch_pp(const ConvGemmParams& p, hipStream_t stream) {
   const bool gather = !(p.ks == 1 && p.pad == 0);
-  static unsigned long long attr_done_g = 0, attr_done_p = 0, attr_done_c = 0, attr_done_s = 0;
-  if (int rc = af_ensure_dynamic_lds(attr_done_g, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, true>), C::LDS_BYTES)) return rc;
-  if (int rc = af_ensure_dynamic_lds(attr_done_p, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, false>), C::LDS_BYTES)) return rc;
-  if (int rc = af_ensure_dynamic_lds(attr_done_c, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, false, 1>), C::LDS_BYTES)) return rc;
-  if (int rc = af_ensure_dynamic_lds(attr_done_s, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, false, 2>), C::LDS_BYTES)) return rc;
+  const bool ns = g_af_knobs.pp_sched != 0;
   dim3 grid(((p.M + 255) / 256) * (p.N / BN), 1, p.splitk > 1 ? p.splitk : 1);
   if (p.ln_stats || p.ln_stats_out) {
     // LayerNorm-fused variants: plain (1x1) GEMMs on one K slice only; the caller (af_model.hip) asks the planner first
@@ -1643,12 +1706,11 @@ template <int BN> static int launch_pp(const ConvGemmParams& p, hipStream_t stre
       af_set_error_msg("conv_gemm: LayerNorm-fused launch needs a 1x1 GEMM without split-K");
       return -1;
     }
-    if (p.ln_stats) hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, false, 1>), grid, dim3(512), C::LDS_BYTES, stream, p);
-    else hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, false, 2>), grid, dim3(512), C::LDS_BYTES, stream, p);
-  } else if (gather) hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, true>), grid, dim3(512), C::LDS_BYTES, stream, p);
-  else hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, false>), grid, dim3(512), C::LDS_BYTES, stream, p);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
+    if (p.ln_stats) return ns ? launch_pp_one<BN, 1, false, true>(p, grid, stream) : launch_pp_one<BN, 1, false, false>(p, grid, stream);
+    return ns ? launch_pp_one<BN, 2, false, true>(p, grid, stream) : launch_pp_one<BN, 2, false, false>(p, grid, stream);
+  }
+  if (gather) return ns ? launch_pp_one<BN, 0, true, true>(p, grid, stream) : launch_pp_one<BN, 0, true, false>(p, grid, stream);
+  return ns ? launch_pp_one<BN, 0, false, true>(p, grid, stream) : launch_pp_one<BN, 0, false, false>(p, grid, stream);
 }
 
 template <int BN> static int launch_pp8(const ConvGemmParams& p, hipStream_t stream) {
@@ -1704,6 +1766,8 @@ static int launch_conv_gemm_fp8(ConvGemmParams p, hipStream_t stream, const AfGe
   p.group_m = pl.group_m > 0 ? pl.group_m : 1;
   p.pp_epilogue = g_af_knobs.pp_direct < 0 ? 0 : (g_af_knobs.pp_direct ? 2 : 1);
   p.k_tap_inner = 1;
+  p.pp_prio = g_af_knobs.pp_prio;
+  p.fast_taps = g_af_knobs.conv_fast_taps;
   AfProfScope prof(AF_K_PP_FP8, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K),
                    (double)p.M * p.Cin + (double)p.N * p.K + (double)p.M * p.N * 2.0);
   const int rc = pl.tile == 4 ? launch_pp8<128>(p, stream) : launch_pp8<160>(p, stream);
@@ -1779,6 +1843,8 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   p.group_m = pl.group_m > 0 ? pl.group_m : 1;
   p.pp_epilogue = g_af_knobs.pp_direct < 0 ? 0 : (g_af_knobs.pp_direct ? 2 : 1);
   p.k_tap_inner = (p.ks > 1 && g_af_knobs.conv_tap_inner) ? 1 : 0;
+  p.pp_prio = g_af_knobs.pp_prio;
+  p.fast_taps = g_af_knobs.conv_fast_taps;
   const int prof_cls = pl.tile == 5 ? ((p.ks == 1 && p.pad == 0) ? AF_K_PP160_PLAIN : AF_K_PP160_GATHER)
                                      : (pl.tile == 4 ? AF_K_PP128 : AF_K_CONV_GEMM);
   AfProfScope prof(prof_cls, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K) * batch,

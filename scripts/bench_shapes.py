@@ -20,8 +20,15 @@ ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--only", default="")
 ap.add_argument("--bf", type=int, default=16)
+ap.add_argument("--knob", action="append", default=[], help="name=value (af_knob_set), repeatable: A/B a kernel variant")
+ap.add_argument("--lib", default="", help="lab only: another build of libadaface_hip.so to time on the same box (A/B of a structural change)")
 args = ap.parse_args()
+if args.lib:
+    _lib._LIB_PATH = Path(args.lib).resolve()
 lib = _lib.load()
+for kv in args.knob:
+    k, v = kv.split("=")
+    _lib.set_knob(k, int(v))
 dev = torch.device("cuda:0")
 Bf = args.bf
 
