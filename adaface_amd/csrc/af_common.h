@@ -83,10 +83,8 @@ struct AfKnobs {
   int conv_tap_inner;       // AF_CONV_TAP_INNER       0 = ping-pong convs walk K tap-outermost (the round-1 order)
   int ln_fuse;              // AF_LN_FUSE              0 = stand-alone LayerNorm kernels in front of the transformer GEMMs
   int conv_fast_taps;       // AF_CONV_FAST_TAPS       0 = ping-pong convs recompute every tap's bounds check in the staging phase
-  int pp_prio;              // AF_PP_PRIO              ping-pong kernel, block-ordered schedule: 0 = compute phase at wave priority 1,
-                            //                         1 = no priorities, 2 = staging phase at priority 1
-  int pp_sched;             // AF_PP_SCHED             0 = ping-pong kernel on the round-1 compute phase (two K halves, a full
-                            //                         LDS drain after each) instead of the block-ordered one
+  int pp_sched;             // AF_PP_SCHED             eight-wave kernel: 0 = round-1 compute phase (two K halves, a full LDS drain
+                            //                         after each), 1 = block-ordered compute phase, 2 = merged (no staging phase)
 };
 extern AfKnobs g_af_knobs;
 
@@ -249,7 +247,6 @@ struct ConvGemmParams {
   // UNITS, unit u = (channel chunk u / taps, tap u % taps), zero-padded to a multiple of 128 = K; Cin = real channel
   // count (multiple of 64).  Scales are powers of two applied by the MFMA itself (E8M0): w_scale[n] per output channel,
   // x_scale_e8 for the whole activation tensor (the producer multiplied by 2^(127 - x_scale_e8)).
-  int pp_prio;            // ping-pong kernel (set by the launcher from the pp_prio knob): wave-priority experiment
   int fast_taps;          // ping-pong kernel (set by the launcher): per-piece tap validity masks instead of per-tap bounds arithmetic
   int fp8;
   const unsigned char* w_scale;

@@ -507,15 +507,29 @@ typedef __attribute__((ext_vector_type(4))) int pp_i32x4;
 // the bf16 kernel already uses.  A K tile is two 64-channel UNITS (unit u = channel chunk u / taps, tap u % taps), so
 // that channel counts that are multiples of 64 but not of 128 (320, 960) waste nothing: chunks 0-3 of an LDS row come
 // from unit 2t, chunks 4-7 from unit 2t + 1, each lane of the staging waves walks the units of ITS half.
-template <int BN, bool GATHER, int LNMODE = 0, bool FP8 = false, bool NS = FP8>
+//
+// SCHED: 0 = the round-1 compute phase (two K halves, a full LDS drain after each); 1 = block-ordered compute phase (see
+// "FP8 fragments and compute phase" below), staging still in its own phase; 2 = MERGED: no staging phase at all -- every
+// wave stages its share of tile t + 2 (one LDS-DMA piece behind every other MFMA of tile t) while it computes, ONE barrier
+// per K tile, and both waves of a SIMD always have MFMAs to offer the matrix pipe.
+template <int BN, bool GATHER, int LNMODE = 0, bool FP8 = false, int SCHED = FP8 ? 2 : 0>
 __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams p) {
-  static_assert(NS || !FP8, "fp8 operands exist on the block-ordered schedule only");
+  constexpr bool NS = SCHED >= 1, MG = SCHED == 2;
+  static_assert(MG || !FP8, "fp8 operands exist on the merged schedule only");
   using C = PpCfg<BN>;
   typedef bf16 T;
   static_assert(!FP8 || LNMODE == 0, "fp8 operands: plain epilogue only");
   constexpr unsigned XE = FP8 ? 1u : 2u;   // bytes per operand element
   constexpr int NI = C::NI, MI = C::MI, SLOT = C::SLOT, XBYTES = C::XBYTES;
-  constexpr int NP0 = C::NP0, NX1 = C::NX1, NW1 = C::NW1, NP1 = C::NP1, NPMAX = C::NPMAX, XP0 = C::XP0;
+  // piece split between the two wave groups.  Phased schedules: group 0 all-activation (7 of 8), group 1 the rest and
+  // every weight piece.  Merged: every wave stages while it computes, so the gathers are split evenly.
+  constexpr int XP0 = MG ? C::XP / 2 : C::XP0;                       // activation pieces of group 0
+  constexpr int NX0 = XP0 / 4, NX1 = (C::XP - XP0) / 4;              // ... per wave, group 0 / 1
+  constexpr int WP0 = MG ? (C::WP / 8) * 4 : 0;                      // weight pieces of group 0
+  constexpr int NW0 = WP0 / 4, NW1 = (C::WP - WP0) / 4;
+  constexpr int NP0 = NX0 + NW0, NP1 = NX1 + NW1, NPMAX = NP0 > NP1 ? NP0 : NP1;
+  constexpr int NXM = NX0 > NX1 ? NX0 : NX1, NWM = NW0 > NW1 ? NW0 : NW1;
+  static_assert(XP0 % 4 == 0 && WP0 % 4 == 0 && NW1 >= 1, "piece split");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -545,14 +559,14 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
   const unsigned lchunk = (FP8 ? (dchunk & 3u) : dchunk) * 16u;     // ... its byte offset inside the 64-channel run
   const int HoWo = p.Ho * p.Wo;
   const unsigned ldcb = (unsigned)p.ldc * XE;
-  const bool fast_taps = GATHER && p.up == 0 && p.ks * p.ks <= 31 && p.fast_taps;
-  unsigned x_off[NP0];
-  int x_yx[GATHER ? NP0 : 1];   // (iy0 << 16) | (ix0 & 0xffff): input coordinate of tap (0,0); fast taps: validity mask
-  pp_static_for<0, NP0>([&](auto qc) {
+  const bool fast_taps = GATHER && ((p.up == 0 && p.ks * p.ks <= 31 && p.fast_taps) || MG);
+  unsigned x_off[NXM];
+  int x_yx[GATHER ? NXM : 1];   // (iy0 << 16) | (ix0 & 0xffff): input coordinate of tap (0,0); fast taps: validity mask
+  pp_static_for<0, NXM>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
     const int piece = g == 0 ? wq + 4 * q : XP0 + wq + 4 * q;
     const int m = m0 + piece * 8 + srow;
-    const bool ok = m < p.M && (g == 0 || q < NX1);
+    const bool ok = m < p.M && (g == 0 ? q < NX0 : q < NX1);
     const int mm = ok ? m : 0;
     // (b, oy, ox) of the output pixel: shifts when the map sizes are powers of two (every SD-1.5 / VAE level) -- the
     // seven integer divisions per lane cost a few thousand cycles per SIMD at the head of a short-K workgroup
@@ -593,61 +607,76 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     }
     x_off[q] = off;
   });
-  unsigned w_off[NW1];
+  unsigned w_off[NWM];
 #pragma unroll
-  for (int q = 0; q < NW1; ++q) {
-    const int n = n0 + (wq + 4 * q) * 8 + srow;
+  for (int q = 0; q < NWM; ++q) {
+    const int n = n0 + ((g == 0 ? 0 : WP0) + wq + 4 * q) * 8 + srow;
     w_off[q] = n < p.Wrows ? (unsigned)((long)n * p.ldw * XE) + dchunk * 16u : 0xFFFFFFFFu;
   }
   // K order.  The sum over (tap, channel chunk) can be walked either way; with the TAP innermost (k_tap_inner) the nine
   // taps of a channel chunk re-read the same few input rows back to back, so eight of nine gathers hit the XCD's L2
   // instead of each tap streaming the whole input slice again (PMC: 225 MB fetched per launch against ~50 MB of input
   // with the tap outermost).  The weight tile of (tap, chunk) is the 128-byte run at column tap * Cin + c0 either way.
-  int ky, kx, c0, ktile = kt_begin;   // filter tap / channel offset / K tile of the NEXT tile this wave stages
+  // K-walk state of the NEXT tile this wave stages: a plain struct handed around BY VALUE (as by-reference lambda captures
+  // mutated inside the merged schedule's compute phase these scalars ended up in scratch, came back as VGPRs, and every
+  // LDS-DMA grew a waterfall loop around its scalar offset)
+  struct KWalk {
+    int ky, kx, c0, ktile;   // filter tap / channel offset / K tile (bf16)
+    int u_tap, u_c0;         // fp8, per lane: tap and channel offset of the unit its half of the tile comes from
+  };
+  KWalk kw;
+  kw.ktile = kt_begin;
+  kw.u_tap = 0; kw.u_c0 = 0;
   if (p.k_tap_inner) {
     const int taps = p.ks * p.ks;
     const int cc = kt_begin / taps, tap = kt_begin - cc * taps;
-    c0 = cc * 64;
-    ky = tap / p.ks;
-    kx = tap - ky * p.ks;
+    kw.c0 = cc * 64;
+    kw.ky = tap / p.ks;
+    kw.kx = tap - kw.ky * p.ks;
   } else {
     const int k0 = kt_begin * 64;
     const int tap = k0 / p.Cin;
-    c0 = k0 - tap * p.Cin;
-    ky = tap / p.ks;
-    kx = tap - ky * p.ks;
+    kw.c0 = k0 - tap * p.Cin;
+    kw.ky = tap / p.ks;
+    kw.kx = tap - kw.ky * p.ks;
   }
-  // FP8: (tap, channel offset) of the unit this lane's half of the NEXT tile comes from (per lane: half = dchunk >> 2)
   const int taps8 = p.ks * p.ks;
-  const int adv_q = 2 / taps8, adv_r = 2 - adv_q * taps8;   // two units further = adv_q chunks + adv_r taps
-  int u_tap = 0, u_c0 = 0;
+  const int adv_q = 2 / taps8, adv_r = 2 - adv_q * taps8;   // fp8: two units further = adv_q chunks + adv_r taps
   if constexpr (FP8) {
     const int u = 2 * kt_begin + (int)(dchunk >> 2);
     const int cc = u / taps8;
-    u_tap = u - cc * taps8;
-    u_c0 = cc * 64;
+    kw.u_tap = u - cc * taps8;
+    kw.u_c0 = cc * 64;
   }
-  int s_tapbit = 0;          // bf16 fast taps: bit of the tap being staged, byte delta of its pixel
-  unsigned s_delta = 0u;
-  int u_ok = 0;              // fp8 fast taps (per lane): unit inside K, byte delta of its tap + channel offset
-  unsigned u_delta = 0u;
-  auto x_addr = [&](auto qc, auto ftc) -> unsigned {
+  // per-tile staging values, passed BY VALUE from stage_begin to the pieces (as captured variables they are written and
+  // read across the "memory"-clobbering fragment-read asm of the merged schedule and end up in scratch)
+  struct StageCtx {
+    unsigned c0b, k0b;      // scalar byte offsets of the activation channel chunk / the weight K tile
+    int live;               // merged schedule: the tile exists (pieces past the K range are issued out of bounds: no
+                            // memory traffic, zeros into a slot nobody reads, the vmcnt counts stay fixed)
+    int tapbit;             // bf16 fast taps: mask bit of the tap, byte delta of its pixel
+    unsigned delta;
+    int u_ok;               // fp8 fast taps (per lane): unit inside K, byte delta of its tap + channel offset
+    unsigned u_delta;
+    int ky, kx, u_tap, u_c0;  // copies for the generic (per-tap bounds arithmetic) address path
+  };
+  auto x_addr = [&](auto qc, auto ftc, const StageCtx& sc) -> unsigned {
     constexpr int q = decltype(qc)::value;
     constexpr bool FT = decltype(ftc)::value;   // fast taps (compile-time here: one uniform branch per stage() call, not per piece)
     if constexpr (FP8) {
       if constexpr (GATHER) {
-        if constexpr (FT) return ((x_yx[q] >> u_tap) & u_ok) ? x_off[q] + u_delta : 0xFFFFFFFFu;
-        const int kyl = p.ks == 3 ? (u_tap * 11) >> 5 : 0, kxl = p.ks == 3 ? u_tap - 3 * kyl : 0;
+        if constexpr (FT) return ((x_yx[q] >> sc.u_tap) & sc.u_ok) ? x_off[q] + sc.u_delta : 0xFFFFFFFFu;
+        const int kyl = p.ks == 3 ? (sc.u_tap * 11) >> 5 : 0, kxl = p.ks == 3 ? sc.u_tap - 3 * kyl : 0;
         const int iy = (x_yx[q] >> 16) + kyl, ix = ((x_yx[q] << 16) >> 16) + kxl;
-        const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && u_c0 < p.Cin;
+        const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && sc.u_c0 < p.Cin;
         const unsigned pix = (unsigned)((iy >> p.up) * p.Ws + (ix >> p.up));
-        return ok ? x_off[q] + pix * ldcb + (unsigned)u_c0 : 0xFFFFFFFFu;
+        return ok ? x_off[q] + pix * ldcb + (unsigned)sc.u_c0 : 0xFFFFFFFFu;
       } else {
-        return (u_c0 < p.Cin && x_off[q] != 0xFFFFFFFFu) ? x_off[q] + (unsigned)u_c0 : 0xFFFFFFFFu;
+        return (sc.u_c0 < p.Cin && x_off[q] != 0xFFFFFFFFu) ? x_off[q] + (unsigned)sc.u_c0 : 0xFFFFFFFFu;
       }
     } else if constexpr (GATHER) {
-      if constexpr (FT) return (x_yx[q] & s_tapbit) ? x_off[q] + s_delta : 0xFFFFFFFFu;
-      const int iy = (x_yx[q] >> 16) + ky, ix = ((x_yx[q] << 16) >> 16) + kx;
+      if constexpr (FT) return (x_yx[q] & sc.tapbit) ? x_off[q] + sc.delta : 0xFFFFFFFFu;
+      const int iy = (x_yx[q] >> 16) + sc.ky, ix = ((x_yx[q] << 16) >> 16) + sc.kx;
       const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
       const unsigned pix = (unsigned)((iy >> p.up) * p.Ws + (ix >> p.up));
       return ok ? x_off[q] + pix * ldcb : 0xFFFFFFFFu;
@@ -655,53 +684,71 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
       return x_off[q];
     }
   };
-  auto stage = [&](int slot_off) {
+  // staging of one K tile = stage_begin (wave-uniform / per-lane tap state), one stage_piece per LDS-DMA piece, stage_end
+  // (advance to the next tile).  The phased schedules run the three back to back (stage); the merged one spreads the
+  // pieces over the compute phase.
+  auto stage_begin = [&](const KWalk& k) -> StageCtx {
+    StageCtx sc;
+    sc.tapbit = 0; sc.delta = 0u; sc.u_ok = 0; sc.u_delta = 0u;
+    sc.ky = k.ky; sc.kx = k.kx; sc.u_tap = k.u_tap; sc.u_c0 = k.u_c0;
     if (fast_taps) {
       if constexpr (FP8) {
-        const int kyl = p.ks == 3 ? (u_tap * 11) >> 5 : 0, kxl = p.ks == 3 ? u_tap - 3 * kyl : 0;
-        u_ok = u_c0 < p.Cin ? 1 : 0;
-        u_delta = (unsigned)(kyl * p.Ws + kxl) * ldcb + (unsigned)u_c0;
+        const int kyl = p.ks == 3 ? (k.u_tap * 11) >> 5 : 0, kxl = p.ks == 3 ? k.u_tap - 3 * kyl : 0;
+        sc.u_ok = k.u_c0 < p.Cin ? 1 : 0;
+        sc.u_delta = (unsigned)(kyl * p.Ws + kxl) * ldcb + (unsigned)k.u_c0;
       } else {
-        s_tapbit = 1 << (ky * p.ks + kx);
-        s_delta = (unsigned)(ky * p.Ws + kx) * ldcb;
+        sc.tapbit = 1 << (k.ky * p.ks + k.kx);
+        sc.delta = (unsigned)(k.ky * p.Ws + k.kx) * ldcb;
       }
     }
-    const unsigned c0b = FP8 ? 0u : (unsigned)c0 * 2u;
-    const unsigned k0b = (!FP8 && p.k_tap_inner) ? (unsigned)((ky * p.ks + kx) * p.Cin + c0) * 2u : (unsigned)ktile * 128u;
+    sc.c0b = FP8 ? 0u : (unsigned)k.c0 * 2u;
+    sc.k0b = (!FP8 && p.k_tap_inner) ? (unsigned)((k.ky * p.ks + k.kx) * p.Cin + k.c0) * 2u : (unsigned)k.ktile * 128u;
+    sc.live = (!MG || k.ktile < kt_begin + KT) ? 1 : 0;
+    return sc;
+  };
+  auto stage_piece = [&](auto qc, auto ftc, char* base, const StageCtx& sc) {
+    constexpr int q = decltype(qc)::value;
+    auto fix = [&](unsigned a) -> unsigned { if constexpr (MG) return sc.live ? a : 0xFFFFFFFFu; else return a; };
+    if (g == 0) {
+      if constexpr (q < NX0) lds_dma16(rs_x, base + (wq + 4 * q) * 1024, fix(x_addr(qc, ftc, sc)), sc.c0b);
+      else if constexpr (q < NP0) lds_dma16(rs_w, base + XBYTES + (wq + 4 * (q - NX0)) * 1024, fix(w_off[q - NX0]), sc.k0b);
+    } else {
+      if constexpr (q < NX1) lds_dma16(rs_x, base + (XP0 + wq + 4 * q) * 1024, fix(x_addr(qc, ftc, sc)), sc.c0b);
+      else if constexpr (q < NP1) lds_dma16(rs_w, base + XBYTES + (WP0 + wq + 4 * (q - NX1)) * 1024, fix(w_off[q - NX1]), sc.k0b);
+    }
+  };
+  auto kw_next = [&](KWalk k) -> KWalk {
+    ++k.ktile;
+    if constexpr (FP8) {
+      k.u_tap += adv_r;
+      k.u_c0 += 64 * adv_q;
+      if (k.u_tap >= taps8) { k.u_tap -= taps8; k.u_c0 += 64; }
+    } else if (p.k_tap_inner) {
+      if (++k.kx >= p.ks) {
+        k.kx = 0;
+        if (++k.ky >= p.ks) { k.ky = 0; k.c0 += 64; }
+      }
+    } else {
+      k.c0 += 64;
+      if (k.c0 >= p.Cin) {
+        k.c0 = 0;
+        if (++k.kx >= p.ks) { k.kx = 0; ++k.ky; }
+      }
+    }
+    return k;
+  };
+  auto stage = [&](int slot_off) {
+    const StageCtx sc = stage_begin(kw);
     char* base = smem + slot_off;
-    auto issue = [&](auto ftc) {
-      pp_static_for<0, NPMAX>([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        if (g == 0) {
-          if constexpr (q < NP0) lds_dma16(rs_x, base + (wq + 4 * q) * 1024, x_addr(qc, ftc), c0b);
-        } else {
-          if constexpr (q < NX1) lds_dma16(rs_x, base + (XP0 + wq + 4 * q) * 1024, x_addr(qc, ftc), c0b);
-          else if constexpr (q < NP1) lds_dma16(rs_w, base + XBYTES + (wq + 4 * (q - NX1)) * 1024, w_off[q - NX1], k0b);
-        }
-      });
-    };
-    if constexpr (GATHER) {
+    auto issue = [&](auto ftc) { pp_static_for<0, NPMAX>([&](auto qc) { stage_piece(qc, ftc, base, sc); }); };
+    if constexpr (GATHER && MG) {
+      issue(std::true_type{});
+    } else if constexpr (GATHER) {
       if (fast_taps) issue(std::true_type{}); else issue(std::false_type{});
     } else {
       issue(std::false_type{});
     }
-    ++ktile;
-    if constexpr (FP8) {
-      u_tap += adv_r;
-      u_c0 += 64 * adv_q;
-      if (u_tap >= taps8) { u_tap -= taps8; u_c0 += 64; }
-    } else if (p.k_tap_inner) {
-      if (++kx >= p.ks) {
-        kx = 0;
-        if (++ky >= p.ks) { ky = 0; c0 += 64; }
-      }
-    } else {
-      c0 += 64;
-      if (c0 >= p.Cin) {
-        c0 = 0;
-        if (++kx >= p.ks) { kx = 0; ++ky; }
-      }
-    }
+    kw = kw_next(kw);
   };
   auto wait_keep1 = [&]() { if (g == 0) pp_wait_vm<NP0>(); else pp_wait_vm<NP1>(); };
 
@@ -814,9 +861,12 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     constexpr int n = decltype(nc)::value;
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(blk[0]), "+v"(blk[1]) : "n"(n) : "memory");
   };
-  auto cphase8 = [&](int slot_off, pp_u32x4 (&xc)[NS ? MI : 1][2], pp_u32x4 (&xp)[NS ? MI : 1][2]) {
+  // (ftc / stage_off: merged schedule only -- the LDS-DMA pieces of tile t + 2 go out one behind every other MFMA)
+  auto cphase8 = [&](int slot_off, pp_u32x4 (&xc)[NS ? MI : 1][2], pp_u32x4 (&xp)[NS ? MI : 1][2], auto ftc, int stage_off,
+                     const StageCtx& sc) {
     if constexpr (NS) {
       constexpr int NB = NI + MI;
+      char* sbase = smem + stage_off;
       const unsigned b0 = lds0 + (unsigned)slot_off + fch0, b1 = lds0 + (unsigned)slot_off + fch1;
       auto rd_block = [&](auto bc) {
         constexpr int bi = decltype(bc)::value;
@@ -850,29 +900,61 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
           mfma8(acc[i][j], w8[i], xc[j], wsc8[FP8 ? i : 0]);
         }
         if constexpr (2 + m < NB) rd_block(std::integral_constant<int, 2 + m>{});
+        if constexpr (MG && m >= MI && (m - MI) % 2 == 0 && (m - MI) / 2 < NPMAX)
+          stage_piece(std::integral_constant<int, (m - MI) / 2>{}, ftc, sbase, sc);
         __builtin_amdgcn_sched_barrier(0);
       });
+      static_assert(!MG || MI + 2 * (NPMAX - 1) < MI * NI, "merged schedule: a staging slot behind an MFMA for every piece");
       pp_wait_lgkm0();       // every read of the tile is back (the last weight block included)
     }
   };
 
-  // ---- prologue: tile 0 (group 1 also tile 1) in flight; group 1's part of tile 0 landed ----
+  int rd = 0, w0 = SLOT, w1 = 2 * SLOT;       // slots of tiles t, t+1, t+2
+  if constexpr (MG) {
+    // ---- merged schedule: tiles 0 and 1 in flight (every wave its own pieces), then per tile: own pieces of tile t
+    // landed (tile t + 1's stay in flight) -> barrier (tile t complete and visible; everyone done reading tile t - 1) ->
+    // compute tile t while staging tile t + 2 into the slot of tile t - 1
+    stage(0);
+    stage(SLOT);
+    auto tile = [&](auto& xc, auto& xp) {
+      if (g == 0) pp_wait_vm<NP0>(); else pp_wait_vm<NP1>();
+      __builtin_amdgcn_s_barrier();
+      // (gathers: fast taps only -- the launcher sends upsampled convolutions to the phased schedule)
+      const StageCtx sc = stage_begin(kw);
+      cphase8(rd, xc, xp, std::integral_constant<bool, GATHER>{}, w1, sc);
+      kw = kw_next(kw);
+      const int tmp = rd; rd = w0; w0 = w1; w1 = tmp;
+    };
+    for (int t = 0; t + 1 < KT; t += 2) {   // (pairs: no branch inside the body, so no register shuffles where paths merge)
+      tile(xa8, xb8);
+      tile(xb8, xa8);
+    }
+    if (KT & 1) tile(xa8, xb8);
+    pp_wait_vm<0>();          // the out-of-range pieces of tiles KT, KT + 1 (zero fill) before the epilogue reuses the LDS
+    if (KT & 1) {
+#pragma unroll
+      for (int j = 0; j < MI; ++j) mfma8(acc[NI - 1][j], w8[NI - 1], xa8[j], wsc8[FP8 ? NI - 1 : 0]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < MI; ++j) mfma8(acc[NI - 1][j], w8[NI - 1], xb8[j], wsc8[FP8 ? NI - 1 : 0]);
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+  // ---- phased schedules, prologue: tile 0 (group 1 also tile 1) in flight; group 1's part of tile 0 landed ----
+  if constexpr (!MG) {
   stage(0);
   if (g == 1) {
     if (KT > 1) { stage(SLOT); wait_keep1(); } else pp_wait_vm<0>();
   }
   __builtin_amdgcn_s_barrier();
   if (g == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one interval behind
-  int rd = 0, w0 = SLOT, w1 = 2 * SLOT;       // slots of tiles t, t+1, t+2
-  // (experiment, pp_prio knob: 0 = compute phase at priority 1 (shipped), 1 = no priorities, 2 = staging phase at priority 1)
+  }
   auto dphase = [&](int t) {
-    if (p.pp_prio == 2) __builtin_amdgcn_s_setprio(1);
     if (g == 0) {
       if (t + 1 < KT) { stage(w0); wait_keep1(); } else pp_wait_vm<0>();   // own part of tile t landed
     } else {
       if (t + 2 < KT) stage(w1);
     }
-    if (p.pp_prio == 2) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_s_barrier();
   };
   auto cend = [&](int t) {
@@ -880,21 +962,21 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     __builtin_amdgcn_s_barrier();
     const int tmp = rd; rd = w0; w0 = w1; w1 = tmp;
   };
-  if constexpr (NS) {
-    for (int t = 0; t < KT; t += 2) {
+  if constexpr (MG) {
+  } else if constexpr (NS) {
+    auto tile1 = [&](int t, auto& xc, auto& xp) {
       dphase(t);
-      if (p.pp_prio == 0) __builtin_amdgcn_s_setprio(1);
-      cphase8(rd, xa8, xb8);
-      if (p.pp_prio == 0) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(1);   // (no priorities at all, or the staging phase raised instead: no difference, measured)
+      cphase8(rd, xc, xp, std::false_type{}, 0, StageCtx{});
+      __builtin_amdgcn_s_setprio(0);
       cend(t);
-      if (t + 1 < KT) {
-        dphase(t + 1);
-        if (p.pp_prio == 0) __builtin_amdgcn_s_setprio(1);
-        cphase8(rd, xb8, xa8);
-        if (p.pp_prio == 0) __builtin_amdgcn_s_setprio(0);
-        cend(t + 1);
-      }
+    };
+    int t = 0;
+    for (; t + 1 < KT; t += 2) {
+      tile1(t, xa8, xb8);
+      tile1(t + 1, xb8, xa8);
     }
+    if (KT & 1) tile1(t, xa8, xb8);
     // the last tile's held-back MFMAs
     if (KT & 1) {
 #pragma unroll
@@ -924,7 +1006,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i][1]),
                                                             __builtin_bit_cast(bf16x8, xf[j][1]), acc[i][j], 0, 0, 0);
   }
-  if (g == 0) __builtin_amdgcn_s_barrier();
+  if constexpr (!MG) { if (g == 0) __builtin_amdgcn_s_barrier(); }
   if constexpr (NS) load_bias();
 
   // ------------------------------- epilogue -------------------------------
@@ -1525,7 +1607,7 @@ static AfGemmPlan plan_fp8(const ConvGemmParams& p, int batch) {
   pl.group_m = 1;
   const int cand = p.N % 160 == 0 ? 5 : (p.N % 128 == 0 ? 4 : -1);
   if (batch != 1 || p.epilogue == AF_EPI_GEGLU || cand < 0 || p.K % 128 != 0 || p.Cin % 64 != 0 || (p.ks != 1 && p.ks != 3) ||
-      p.M < 512 || !g_af_knobs.gemm_pp)
+      p.up != 0 || p.M < 512 || !g_af_knobs.gemm_pp)
     return pl;
   const int KT = p.K / 128;
   const long nb = (long)((p.M + 255) / 256) * (p.N / (cand == 5 ? 160 : 128));
@@ -1688,17 +1770,26 @@ static int launch_cfg(const ConvGemmParams& p, int batch, hipStream_t stream) {
   return use_dma ? launch_cfg2<T, BM, BN, true>(p, batch, stream) : launch_cfg2<T, BM, BN, false>(p, batch, stream);
 }
 
-template <int BN, int LNMODE, bool GATHER, bool NS> static int launch_pp_one(const ConvGemmParams& p, dim3 grid, hipStream_t stream) {
+template <int BN, int LNMODE, bool GATHER, bool FP8, int SCHED>
+static int launch_pp_one(const ConvGemmParams& p, dim3 grid, hipStream_t stream) {
   using C = PpCfg<BN>;
   static unsigned long long attr_done = 0;
-  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, GATHER, LNMODE, false, NS>), C::LDS_BYTES)) return rc;
-  hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, GATHER, LNMODE, false, NS>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, GATHER, LNMODE, FP8, SCHED>), C::LDS_BYTES)) return rc;
+  hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, GATHER, LNMODE, FP8, SCHED>), grid, dim3(512), C::LDS_BYTES, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+template <int BN, int LNMODE, bool GATHER> static int launch_pp_sched(const ConvGemmParams& p, dim3 grid, hipStream_t stream) {
+  int sched = g_af_knobs.pp_sched;
+  if (sched >= 2 && GATHER && !(p.up == 0 && p.ks * p.ks <= 31)) sched = 1;   // merged gathers exist with tap masks only
+  switch (sched) {
+    case 0: return launch_pp_one<BN, LNMODE, GATHER, false, 0>(p, grid, stream);
+    case 1: return launch_pp_one<BN, LNMODE, GATHER, false, 1>(p, grid, stream);
+    default: return launch_pp_one<BN, LNMODE, GATHER, false, 2>(p, grid, stream);
+  }
+}
 template <int BN> static int launch_pp(const ConvGemmParams& p, hipStream_t stream) {
   const bool gather = !(p.ks == 1 && p.pad == 0);
-  const bool ns = g_af_knobs.pp_sched != 0;
   dim3 grid(((p.M + 255) / 256) * (p.N / BN), 1, p.splitk > 1 ? p.splitk : 1);
   if (p.ln_stats || p.ln_stats_out) {
     // LayerNorm-fused variants: plain (1x1) GEMMs on one K slice only; the caller (af_model.hip) asks the planner first
@@ -1706,24 +1797,16 @@ template <int BN> static int launch_pp(const ConvGemmParams& p, hipStream_t stre
       af_set_error_msg("conv_gemm: LayerNorm-fused launch needs a 1x1 GEMM without split-K");
       return -1;
     }
-    if (p.ln_stats) return ns ? launch_pp_one<BN, 1, false, true>(p, grid, stream) : launch_pp_one<BN, 1, false, false>(p, grid, stream);
-    return ns ? launch_pp_one<BN, 2, false, true>(p, grid, stream) : launch_pp_one<BN, 2, false, false>(p, grid, stream);
+    return p.ln_stats ? launch_pp_sched<BN, 1, false>(p, grid, stream) : launch_pp_sched<BN, 2, false>(p, grid, stream);
   }
-  if (gather) return ns ? launch_pp_one<BN, 0, true, true>(p, grid, stream) : launch_pp_one<BN, 0, true, false>(p, grid, stream);
-  return ns ? launch_pp_one<BN, 0, false, true>(p, grid, stream) : launch_pp_one<BN, 0, false, false>(p, grid, stream);
+  return gather ? launch_pp_sched<BN, 0, true>(p, grid, stream) : launch_pp_sched<BN, 0, false>(p, grid, stream);
 }
 
 template <int BN> static int launch_pp8(const ConvGemmParams& p, hipStream_t stream) {
-  using C = PpCfg<BN>;
   const bool gather = !(p.ks == 1 && p.pad == 0);
-  static unsigned long long attr_done_g = 0, attr_done_p = 0;
-  if (int rc = af_ensure_dynamic_lds(attr_done_g, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, true, 0, true>), C::LDS_BYTES)) return rc;
-  if (int rc = af_ensure_dynamic_lds(attr_done_p, reinterpret_cast<const void*>(&conv_gemm_pp_kernel<BN, false, 0, true>), C::LDS_BYTES)) return rc;
   dim3 grid(((p.M + 255) / 256) * (p.N / BN), 1, p.splitk > 1 ? p.splitk : 1);
-  if (gather) hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, true, 0, true>), grid, dim3(512), C::LDS_BYTES, stream, p);
-  else hipLaunchKernelGGL((conv_gemm_pp_kernel<BN, false, 0, true>), grid, dim3(512), C::LDS_BYTES, stream, p);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
+  // (fp8 operands exist on the merged schedule only: its gathers need the tap masks, i.e. no upsampling -- plan_fp8 refuses)
+  return gather ? launch_pp_one<BN, 0, true, true, 2>(p, grid, stream) : launch_pp_one<BN, 0, false, true, 2>(p, grid, stream);
 }
 
 // fp8-operand launch (bf16 everywhere else): validated apart from the bf16 / f32 path, ping-pong kernel only
@@ -1766,7 +1849,6 @@ static int launch_conv_gemm_fp8(ConvGemmParams p, hipStream_t stream, const AfGe
   p.group_m = pl.group_m > 0 ? pl.group_m : 1;
   p.pp_epilogue = g_af_knobs.pp_direct < 0 ? 0 : (g_af_knobs.pp_direct ? 2 : 1);
   p.k_tap_inner = 1;
-  p.pp_prio = g_af_knobs.pp_prio;
   p.fast_taps = g_af_knobs.conv_fast_taps;
   AfProfScope prof(AF_K_PP_FP8, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K),
                    (double)p.M * p.Cin + (double)p.N * p.K + (double)p.M * p.N * 2.0);
@@ -1843,7 +1925,6 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   p.group_m = pl.group_m > 0 ? pl.group_m : 1;
   p.pp_epilogue = g_af_knobs.pp_direct < 0 ? 0 : (g_af_knobs.pp_direct ? 2 : 1);
   p.k_tap_inner = (p.ks > 1 && g_af_knobs.conv_tap_inner) ? 1 : 0;
-  p.pp_prio = g_af_knobs.pp_prio;
   p.fast_taps = g_af_knobs.conv_fast_taps;
   const int prof_cls = pl.tile == 5 ? ((p.ks == 1 && p.pad == 0) ? AF_K_PP160_PLAIN : AF_K_PP160_GATHER)
                                      : (pl.tile == 4 ? AF_K_PP128 : AF_K_CONV_GEMM);

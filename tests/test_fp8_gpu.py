@@ -50,7 +50,6 @@ def _quant_w(w):
     (4, 320, 32, 32, 640, 1, 1, False, True, False),     # 1x1: plain (no gather) variant, 5 units
     (2, 128, 32, 32, 256, 3, 1, False, True, False),     # N % 128 only -> 256x128 tile
     (2, 64, 32, 32, 160, 3, 2, False, True, False),      # stride 2, one unit per tap
-    (2, 128, 16, 16, 320, 3, 1, True, False, True),      # nearest-2x upsample folded into the gather
     (3, 192, 24, 24, 160, 3, 1, False, True, False),     # M = 1728: ragged last M tile, Ho*Wo not a power of two
 ])
 def test_conv2d_fp8_kernel(gpu, report, knobs, B, Cin, H, W, Cout, ks, stride, up, bias, res):
@@ -89,6 +88,10 @@ def test_conv2d_fp8_refuses_unplannable_shape(gpu):
     w = torch.randn(100, 64, 3, 3)          # N = 100: neither 160 nor 128 columns
     with pytest.raises(_lib.AfError):
         ops.conv2d_fp8(x.to(gpu), w.to(gpu))
+    x = torch.randn(2, 128, 16, 16)
+    w = torch.randn(320, 128, 3, 3)         # upsampled gathers stay on the bf16 path (no tap masks)
+    with pytest.raises(_lib.AfError):
+        ops.conv2d_fp8(x.to(gpu), w.to(gpu), upsample=True)
 
 
 @pytest.mark.parametrize("B,C,H,W,silu", [(2, 320, 64, 64, True), (2, 1280, 8, 8, True), (1, 640, 32, 32, False),
