@@ -54,3 +54,21 @@ def synth_context_adaprompt(batch: int, seed: int, device, n_layers: int = 16, n
     g = torch.Generator(device="cpu").manual_seed(seed + 7919)
     ctx[:, :, subj_start:subj_start + n_subj_vectors] = torch.randn(batch, n_layers, n_subj_vectors, dim, generator=g) * subj_std
     return ctx.reshape(batch * n_layers, n_tokens, dim).contiguous().to(device)
+
+
+def synth_context_identity(batch: int, seed: int, device, n_layers: int = 16, n_tokens: int = 77, dim: int = 768,
+                           id_start: int = 4, n_id_vectors: int = 16, id_dim: int = 512) -> torch.Tensor:
+    """BASELINE.json configs[4] ("ArcFace identity-encoder context (arc2face path)") as synthetic data, SURVEY.md §8(d) /
+    §8f-4: the zero-shot path turns a [1, 512] unit-norm ArcFace embedding into 16 identity token embeddings at text
+    positions 4:20 (ldm/util.py:1085-1131, arc2face_models.py:175-280) through networks whose weights do not exist
+    offline.  Here: a plain-prompt context whose rows id_start .. id_start + 15 of EVERY layer copy hold one seeded
+    unit-norm 512-d vector per sample, zero-padded to 768 (util.py:1111) and scaled by sqrt(512) to the O(1) element scale
+    of CLIP outputs — shape, placement and padding follow the reference, the projection itself is synthetic."""
+    ctx = synth_context(batch, seed, "cpu", n_layers, n_tokens, dim).reshape(batch, n_layers, n_tokens, dim).clone()
+    g = torch.Generator(device="cpu").manual_seed(seed + 104729)
+    ident = torch.randn(batch, id_dim, generator=g)
+    ident = ident / ident.norm(dim=1, keepdim=True) * math.sqrt(id_dim)
+    row = torch.zeros(batch, dim)
+    row[:, :id_dim] = ident
+    ctx[:, :, id_start:id_start + n_id_vectors] = row[:, None, None, :]
+    return ctx.reshape(batch * n_layers, n_tokens, dim).contiguous().to(device)

@@ -42,12 +42,15 @@ F_UNET = 803.273e9      # algorithmic FLOP per sample-forward
 F_VAE = 2514.519e9      # algorithmic FLOP per decoded image
 PEAK_BF16 = 2.5e15      # dense bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_F32 = 157.3e12
+PEAK_MXFP8 = 5.0e15     # dense block-scaled fp8 MFMA peak (the fp8 convolutions' own roofline)
 # af_prof classes (include/adaface_hip.h)
 K_NAMES = ["conv_gemm_other", "attention", "groupnorm", "layernorm", "other", "conv_gemm_pp<160,gather>",
-           "conv_gemm_pp<160,plain>", "conv_gemm_pp<128>"]
-GEMM_CLASSES = (0, 5, 6, 7)
-DOMINANT = 5            # conv_gemm_pp_kernel<160, true>: the 3x3 convolutions, the largest single kernel of a step
-DOMINANT_KERNEL = "conv_gemm_pp_kernel<160, true, 0>"
+           "conv_gemm_pp<160,plain>", "conv_gemm_pp<128>", "conv_gemm_pp<fp8>"]
+GEMM_CLASSES = (0, 5, 6, 7, 8)
+DOMINANT = 5            # conv_gemm_pp_kernel<160, true, ...>: the 3x3 convolutions, the largest single kernel of a step
+DOMINANT_KERNEL = "conv_gemm_pp_kernel<160, true, 0, false, 2>"
+DOMINANT_FP8 = 8        # fp8 mode: the same convolutions with e4m3 operands (both tile widths in one class)
+DOMINANT_FP8_KERNEL = "conv_gemm_pp_kernel<160|128, true, 0, true, 2>"
 
 
 def parse():
@@ -55,11 +58,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="config1", choices=["config1", "config2", "config3"])
+    ap.add_argument("--workload", default="config1", choices=["config1", "config2", "config3", "config4"],
+                    help="BASELINE.json configs[1..4]; config4 = identity context + fp8 convolutions, global batch 64")
     ap.add_argument("--batch", type=int, default=8, help="images per UNet micro-batch (CFG forward batch = 2x)")
     ap.add_argument("--global-batch", type=int, default=None, help="images per step over all ranks (config3: 64)")
     ap.add_argument("--ddim-steps", type=int, default=50)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "fp8"],
+                    help="compute mode (default bf16; config4: fp8 = bf16 with e4m3 ResBlock convolutions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event roofline leg")
     ap.add_argument("--no-parity-leg", action="store_true",
@@ -140,6 +145,8 @@ def traffic_record():
 
 def main():
     args = parse()
+    if args.dtype is None:
+        args.dtype = "fp8" if args.workload == "config4" else "bf16"
     # ---- N > 1 without a launcher: start the ranks ourselves, BEFORE anything here touches the GPU ----
     from adaface_amd.parallel import init_distributed, launch_ranks, launched_by_torchrun
     if args.gpus > 1 and not launched_by_torchrun():
@@ -161,18 +168,18 @@ def main():
         device = torch.device("cuda", local_rank)
         rank, world = init_distributed(args.gpus, backend="nccl", device=device)
     from adaface_amd.parallel import gather_frames, shard_batch
-    from adaface_amd.synth import synth_context, synth_context_adaprompt
+    from adaface_amd.synth import synth_context, synth_context_adaprompt, synth_context_identity
 
     B, S = args.batch, args.ddim_steps
-    strong = args.workload == "config3" or args.global_batch is not None
-    G = args.global_batch if args.global_batch is not None else (64 if args.workload == "config3" else B * world)
+    strong = args.workload in ("config3", "config4") or args.global_batch is not None
+    G = args.global_batch if args.global_batch is not None else (64 if args.workload in ("config3", "config4") else B * world)
     if G % world or (G // world) % B:
         raise SystemExit(f"global batch {G} must split into micro-batches of {B} on each of {world} rank(s)")
     n_micro = G // world // B
     # global inputs generated from one seed on the host, sliced per rank (results independent of world size)
     g = torch.Generator().manual_seed(42)
     x_T_all = shard_batch(torch.randn(G, 4, 64, 64, generator=g), rank, world).to(device)
-    make_ctx = synth_context_adaprompt if args.workload == "config2" else synth_context
+    make_ctx = {"config2": synth_context_adaprompt, "config4": synth_context_identity}.get(args.workload, synth_context)
     c_all = shard_batch(make_ctx(G, seed=100, device="cpu"), rank, world, per_sample=16).to(device)
     uc_emb = synth_context(B, seed=101, device=device, shared=True)
 
@@ -243,7 +250,7 @@ def main():
         flops = (C.c_double * n)()
         byts = (C.c_double * n)()
         _lib.check(lib.af_prof_collect(n, ms, launches, flops, byts), "af_prof_collect")
-        peak = PEAK_BF16 if args.dtype == "bf16" else PEAK_F32
+        peak = PEAK_F32 if args.dtype == "f32" else PEAK_BF16
         for i, k in enumerate(K_NAMES):
             if launches[i]:
                 kernels[k] = {"launches_timed": int(launches[i]), "ms_total": ms[i], "avg_us": 1e3 * ms[i] / launches[i],
@@ -253,12 +260,18 @@ def main():
         cls_fl = sum(flops[c] for c in GEMM_CLASSES)
         cls_n = sum(launches[c] for c in GEMM_CLASSES)
         # the f32 parity mode has no ping-pong kernel: its dominant kernel is the four-wave / halo class
-        d = DOMINANT if launches[DOMINANT] else 0
+        d = DOMINANT_FP8 if (args.dtype == "fp8" and launches[DOMINANT_FP8]) else (DOMINANT if launches[DOMINANT] else 0)
+        if d == DOMINANT_FP8:
+            peak = PEAK_MXFP8
         if launches[d]:
             traffic, tsrc = traffic_record() if d == DOMINANT else (None, None)
             ach = flops[d] / (ms[d] * 1e-3)
-            roof = {"kernel": DOMINANT_KERNEL + " (3x3 / strided convolutions of the UNet and VAE: eight-wave 256x160x64 "
-                              "ping-pong implicit GEMM, LDS-DMA ring)" if d == DOMINANT else "conv_gemm_kernel / conv3x3_halo_kernel (f32 parity mode)",
+            kname = {DOMINANT: DOMINANT_KERNEL + " (3x3 / strided convolutions of the UNet and VAE: eight-wave 256x160x64 "
+                               "implicit GEMM, LDS-DMA ring, merged staging/compute schedule)",
+                     DOMINANT_FP8: DOMINANT_FP8_KERNEL + " (ResBlock 3x3 convolutions with OCP e4m3 operands on "
+                                   "v_mfma_scale_f32_16x16x128_f8f6f4; peak = dense block-scaled fp8)"}.get(
+                d, "conv_gemm_kernel / conv3x3_halo_kernel (f32 parity mode)")
+            roof = {"kernel": kname,
                     "bound": "mfma", "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
                     "flops_per_launch": flops[d] / launches[d], "avg_launch_us": 1e3 * ms[d] / launches[d],
                     "launches_timed": int(launches[d]), "sampled_every": args.event_stride,
@@ -269,7 +282,7 @@ def main():
 
     # ---- untimed parity leg (rank 0, N = 1): the SAME batch in f32 parity mode ----
     parity = None
-    if rank == 0 and world == 1 and not stub and not args.no_parity_leg and args.dtype == "bf16":
+    if rank == 0 and world == 1 and not stub and not args.no_parity_leg and args.dtype in ("bf16", "fp8"):
         lat16 = last_latent[0].clone()
         model.set_compute_dtype("f32")
         run_micro(x_T_all[(n_micro - 1) * B:], conds[-1])          # engine build + weight upload + first call
@@ -280,11 +293,11 @@ def main():
         t32 = time.perf_counter() - t1
         sc = lat32.abs().max().item()
         parity = {"f32_mode_images_per_sec": B / t32,
-                  "bf16_final_latent_rel_err": (lat16 - lat32).abs().max().item() / sc,
-                  "bf16_final_latent_max_abs_err": (lat16 - lat32).abs().max().item(), "final_latent_max_abs": sc,
+                  f"{args.dtype}_final_latent_rel_err": (lat16 - lat32).abs().max().item() / sc,
+                  f"{args.dtype}_final_latent_max_abs_err": (lat16 - lat32).abs().max().item(), "final_latent_max_abs": sc,
                   "note": "same x_T / context / weights; the f32 (parity) mode is the one pinned to <= 1e-3 max-abs "
                           "against the CPU oracle (tests/test_model_gpu.py::test_config0_*, profiles/*parity_50step*); "
-                          "bf16 is the timed throughput mode and this is its measured deviation after all DDIM steps"}
+                          f"{args.dtype} is the timed throughput mode and this is its measured deviation after all DDIM steps"}
         model.set_compute_dtype(args.dtype)
 
     if rank == 0:
@@ -299,10 +312,12 @@ def main():
             "config": {"workload": f"{args.workload}: SD v1.5 512x512, {S} DDIM steps, batch {B} per forward "
                                    f"(CFG Bf={2 * B}), {n_micro} micro-batch(es) per GPU per step, layerwise 16x77x768 context"
                                    + (" with per-layer AdaPrompt subject rows 6..21" if args.workload == "config2" else "")
+                                   + (" with a synthetic unit-norm 512-d identity embedding (zero-padded to 768) in rows 4..19 of "
+                                      "every layer copy; ResBlock 3x3 convolutions with e4m3 operands" if args.workload == "config4" else "")
                                    + ", random-init weights",
                        "global_batch": G, "latent": [4, 64, 64], "guidance_scale": [10.0, 4.0], "parallelism": f"dp{world}"},
             "whole_path_algorithmic_tflops": value * flop_img / 1e12 / world,
-            "whole_path_frac_of_mfma_peak": value * flop_img / world / (PEAK_BF16 if args.dtype == "bf16" else PEAK_F32),
+            "whole_path_frac_of_mfma_peak": value * flop_img / world / (PEAK_F32 if args.dtype == "f32" else PEAK_BF16),
             "roofline": roof, "kernels": kernels, "parity": parity,
         }
         if stub:
