@@ -559,7 +559,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
   const unsigned lchunk = (FP8 ? (dchunk & 3u) : dchunk) * 16u;     // ... its byte offset inside the 64-channel run
   const int HoWo = p.Ho * p.Wo;
   const unsigned ldcb = (unsigned)p.ldc * XE;
-  const bool fast_taps = GATHER && ((p.up == 0 && p.ks * p.ks <= 31 && p.fast_taps) || MG);
+  const bool fast_taps = GATHER && ((p.up == 0 && p.ks * p.ks <= 31 && (p.fast_taps & 1)) || MG);
   unsigned x_off[NXM];
   int x_yx[GATHER ? NXM : 1];   // (iy0 << 16) | (ix0 & 0xffff): input coordinate of tap (0,0); fast taps: validity mask
   pp_static_for<0, NXM>([&](auto qc) {
@@ -698,6 +698,9 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
         sc.u_delta = (unsigned)(kyl * p.Ws + kxl) * ldcb + (unsigned)k.u_c0;
       } else {
         sc.tapbit = 1 << (k.ky * p.ks + k.kx);
+#ifdef AF_LAB_ABLATE
+        if ((p.fast_taps & 0x100) && (k.ky | k.kx)) sc.tapbit = 0;   // only tap (0,0) fetches activations
+#endif
         sc.delta = (unsigned)(k.ky * p.Ws + k.kx) * ldcb;
       }
     }
@@ -862,6 +865,13 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(blk[0]), "+v"(blk[1]) : "n"(n) : "memory");
   };
   // (ftc / stage_off: merged schedule only -- the LDS-DMA pieces of tile t + 2 go out one behind every other MFMA)
+  // Timing ablations (a separate lab build with -DAF_LAB_ABLATE, scripts/lab/ablate_conv.sh; results are WRONG): bits
+  // 4.. of the conv_fast_taps knob: 0x10 no LDS-DMA in the loop, 0x20 no fragment reads, 0x40 no MFMAs, 0x100 see above
+#ifdef AF_LAB_ABLATE
+  const int lab = p.fast_taps >> 4;
+#else
+  constexpr int lab = 0;
+#endif
   auto cphase8 = [&](int slot_off, pp_u32x4 (&xc)[NS ? MI : 1][2], pp_u32x4 (&xp)[NS ? MI : 1][2], auto ftc, int stage_off,
                      const StageCtx& sc) {
     if constexpr (NS) {
@@ -870,6 +880,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
       const unsigned b0 = lds0 + (unsigned)slot_off + fch0, b1 = lds0 + (unsigned)slot_off + fch1;
       auto rd_block = [&](auto bc) {
         constexpr int bi = decltype(bc)::value;
+        if (lab & 2) return;
         if constexpr (bi == 0) {
           w8[0][0] = pp_lds_read128<0>(b0 + w_base);
           w8[0][1] = pp_lds_read128<0>(b1 + w_base);
@@ -887,7 +898,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
       pp_static_for<0, MI * NI>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         if constexpr (m < MI) {
-          mfma8(acc[NI - 1][m], w8[NI - 1], xp[m], wsc8[FP8 ? NI - 1 : 0]);   // held back from the previous tile
+          if (!(lab & 4)) mfma8(acc[NI - 1][m], w8[NI - 1], xp[m], wsc8[FP8 ? NI - 1 : 0]);   // held back from the previous tile
         } else {
           constexpr int i = (m - MI) / MI, j = (m - MI) % MI;
           constexpr int issued = (2 + m) < NB ? (2 + m) : NB;               // blocks issued before this MFMA
@@ -897,11 +908,11 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
             if constexpr (i == 0) wait_block(cnt, xc[j]); else wait_block(cnt, w8[i]);
             if constexpr (i == 0 && j == 0) wait_block(cnt, w8[0]);
           }
-          mfma8(acc[i][j], w8[i], xc[j], wsc8[FP8 ? i : 0]);
+          if (!(lab & 4)) mfma8(acc[i][j], w8[i], xc[j], wsc8[FP8 ? i : 0]);
         }
         if constexpr (2 + m < NB) rd_block(std::integral_constant<int, 2 + m>{});
         if constexpr (MG && m >= MI && (m - MI) % 2 == 0 && (m - MI) / 2 < NPMAX)
-          stage_piece(std::integral_constant<int, (m - MI) / 2>{}, ftc, sbase, sc);
+          if (!(lab & 1)) stage_piece(std::integral_constant<int, (m - MI) / 2>{}, ftc, sbase, sc);
         __builtin_amdgcn_sched_barrier(0);
       });
       static_assert(!MG || MI + 2 * (NPMAX - 1) < MI * NI, "merged schedule: a staging slot behind an MFMA for every piece");

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Lab: time the full SD-1.5 UNet forward at Bf = 16 (bf16, synthetic weights) with a given build of libadaface_hip.so,
+so that two builds (e.g. the round-1 library and HEAD) can be compared on ONE box:
+    python scripts/lab/ab_forward.py [--lib path/to/lib.so] [--reps 20] [--fp8]
+Older builds lack newer entry points: missing symbols are skipped when --lib is given (lab only)."""
+import argparse
+import ctypes as C
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+from adaface_amd import _lib  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--lib", default="")
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--fp8", action="store_true")
+args = ap.parse_args()
+if args.lib:
+    _lib._LIB_PATH = Path(args.lib).resolve()
+    probe = C.CDLL(str(_lib._LIB_PATH))
+    _lib._SIGS[:] = [s for s in _lib._SIGS if hasattr(probe, s[0])]
+from adaface_amd.engine import Engine  # noqa: E402
+from adaface_amd.synth import synth_weights_into  # noqa: E402
+from oracle import ldm_oracle as O  # noqa: E402  (parameter shapes only)
+
+dev = torch.device("cuda:0")
+cfg = O.SD15_UNET
+kw = dict(in_channels=cfg.in_channels, model_channels=cfg.model_channels, out_channels=cfg.out_channels,
+          num_res_blocks=cfg.num_res_blocks, attention_resolutions=cfg.attention_resolutions, channel_mult=cfg.channel_mult,
+          num_heads=cfg.num_heads, context_dim=cfg.context_dim, transformer_depth=cfg.transformer_depth,
+          n_context_layers=cfg.n_context_layers)
+eng = Engine(dtype="bf16", unet=kw)
+synth_weights_into(eng, O.unet_param_shapes(cfg), seed=1, device=dev)
+if args.fp8:
+    eng.set_fp8(True)
+g = torch.Generator().manual_seed(3)
+x = torch.randn(16, 4, 64, 64, generator=g).to(dev)
+t = torch.full((16,), 500, dtype=torch.long, device=dev)
+ctx = torch.randn(16 * 16, 77, 768, generator=g).to(dev)
+eng.set_context(ctx, 16, layerwise=True)
+out = torch.empty_like(x)
+for _ in range(3):
+    eng.unet_forward(x, t, out)
+torch.cuda.synchronize()
+best = 1e9
+for rnd in range(3):
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        eng.unet_forward(x, t, out)
+    torch.cuda.synchronize()
+    best = min(best, (time.perf_counter() - t0) / args.reps)
+print(f"{args.lib or 'HEAD'}{' fp8' if args.fp8 else ''}: UNet forward Bf=16: {best * 1e3:.3f} ms  (-> {8 / (50 * best + 0.026):.2f} images/s at 50 steps + 26 ms VAE)")
