@@ -90,6 +90,7 @@ _SIGS = [
     ("af_fp8_gemm_launches", C.c_int64, []),
     ("af_op_conv2d_fp8", C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 10 + [_P]),
     ("af_op_groupnorm_fp8", C.c_int, [_P, _P, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    ("af_op_layernorm_fp8", C.c_int, [_P, _P, _P, C.c_float, _P, C.c_int64, C.c_int, C.c_int, _P]),
     ("af_op_layernorm", C.c_int, [C.c_int, _P, _P, _P, C.c_float, _P, C.c_int64, C.c_int, _P]),
     ("af_op_attention", C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
     ("af_clip_embed_tokens", C.c_int, [_P, _P, C.c_int64, _P, _P]),

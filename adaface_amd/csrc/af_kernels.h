@@ -15,7 +15,7 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
                         hipStream_t stream, float fp8_mul = 0.f);   // fp8_mul != 0: y is e4m3 bytes of result * fp8_mul
 template <typename T>
 int af_launch_layernorm(const void* x, int ldx, long rows, int Cn, const float* gamma, const float* beta,
-                        float eps, void* y, int ldy, hipStream_t stream);
+                        float eps, void* y, int ldy, hipStream_t stream, float fp8_mul = 0.f);
 
 template <typename T>
 int af_launch_nchw_to_nhwc(const float* x, void* y, int B, int Cn, int HW, int Cpad, float scale, hipStream_t s);

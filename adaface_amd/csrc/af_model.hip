@@ -870,6 +870,8 @@ struct Runner {
   int layernorm(const Norm& N, const Act& x, Act& y) {
     AF_TRY(check(y));
     if (dry) return 0;
+    if (y.f8)
+      return af_launch_layernorm<bf16>(x.p, x.ld, x.npix(), x.C, N.gamma, N.beta, N.eps, y.p, y.ld, s, (float)(1 << AF_FP8_ACT_SHIFT));
     return DISPATCH(dt, af_launch_layernorm<bf16>(x.p, x.ld, x.npix(), x.C, N.gamma, N.beta, N.eps, y.p, y.ld, s),
                     af_launch_layernorm<float>(x.p, x.ld, x.npix(), x.C, N.gamma, N.beta, N.eps, y.p, y.ld, s));
   }
@@ -966,7 +968,13 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out) {
     // --- x = attn1(norm1(x)) + x ---
     Act n = R.alloc_act(B, H, W, C);
     Act qkv = R.alloc_act(B, H, W, 3 * C);
-    if (ln_parts) {
+    if (R.fp8_capable(blk.qkv1, t, qkv)) {
+      // fp8 mode: LayerNorm writes e4m3 and the q / k / v projection multiplies on the block-scaled fp8 MFMA (the
+      // un-folded weights: its producer's row statistics, if any, simply go unused)
+      Act n8 = R.alloc_act8(B, H, W, C);
+      AF_TRY(R.layernorm(blk.ln1, t, n8));
+      AF_TRY(R.conv(blk.qkv1, n8, qkv, 1, 0, nullptr, nullptr, 0));
+    } else if (ln_parts) {
       AF_TRY(finalize(st_t, blk.ln1));
       const Runner::LnArgs ca = consumer(st_t, blk.qkv1_cs, blk.ln1);
       AF_TRY(R.conv(blk.qkv1_ln, t, qkv, 1, 0, nullptr, nullptr, 0, -1, -1, &ca));
@@ -1087,8 +1095,12 @@ static int fold_layernorms(af_handle* h, hipStream_t s) {
 static int ensure_fp8_twins(af_handle* h, hipStream_t s) {
   if (!h->fp8_on || !h->fp8_dirty) return 0;
   if (h->dtype != AF_DTYPE_BF16) { af_set_error_msg("fp8 convolutions need the bf16 storage mode"); return AF_ERR_STATE; }
-  for (auto& r : h->res)
-    for (Linear* L : {&r.c1, &r.c2}) {
+  std::vector<Linear*> twins;
+  for (auto& r : h->res) { twins.push_back(&r.c1); twins.push_back(&r.c2); }
+  for (auto& x : h->xf)      // "fp8 MFMA QKV": the self-attention q / k / v projection (attention.py:195-196, fused qkv1)
+    for (auto& t : x.blocks) twins.push_back(&t.qkv1);
+  for (Linear* L : twins) {
+    {
       if (L->cin_pad % 64 != 0 || (L->ks != 1 && L->ks != 3)) continue;
       if (!L->w8) {
         const int units = L->ks * L->ks * (L->cin_pad / 64);
@@ -1104,6 +1116,7 @@ static int ensure_fp8_twins(af_handle* h, hipStream_t s) {
       }
       AF_TRY(af_launch_quant_weight_fp8(L->w, L->rows_pad, L->ldw, L->cin_pad, L->ks, L->w8, L->k8, L->sc8, s));
     }
+  }
   h->fp8_dirty = false;
   return 0;
 }

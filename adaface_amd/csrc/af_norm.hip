@@ -237,7 +237,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int ldx, long rows, int Cn,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps,
-                                                         T* __restrict__ y, int ldy) {
+                                                         T* __restrict__ y, int ldy, float fp8_mul) {
   constexpr int EPC = 16 / sizeof(T);
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -277,12 +277,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     const int vi = lane + 64 * i;
     if (vi < NV) {
       Vec16<T> o;
+      float ff[EPC];
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
         const int c = vi * EPC + e;
-        o.e[e] = from_f32<T>((to_f32<T>(v[i].e[e]) - mean) * rstd * gamma[c] + beta[c]);
+        ff[e] = (to_f32<T>(v[i].e[e]) - mean) * rstd * gamma[c] + beta[c];
+        o.e[e] = from_f32<T>(ff[e]);
       }
-      *reinterpret_cast<uint4*>(y + row * ldy + vi * EPC) = o.u;
+      if (fp8_mul != 0.f) {   // e4m3 output (ldy in bytes)
+        unsigned char* y8 = reinterpret_cast<unsigned char*>(y) + row * ldy + vi * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) *reinterpret_cast<unsigned*>(y8 + e) = gn_pack4_e4m3(ff[e], ff[e + 1], ff[e + 2], ff[e + 3], fp8_mul);
+      } else {
+        *reinterpret_cast<uint4*>(y + row * ldy + vi * EPC) = o.u;
+      }
     }
   }
 }
@@ -376,7 +384,7 @@ template <typename T, int RL>
 __global__ __launch_bounds__(256) void layernorm_rowgroup_kernel(const T* __restrict__ x, int ldx, long rows, int Cn,
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, float eps,
-                                                                  T* __restrict__ y, int ldy) {
+                                                                  T* __restrict__ y, int ldy, float fp8_mul) {
   constexpr int EPC = 16 / sizeof(T);
   constexpr int RPB = 256 / RL;   // rows per block
   __shared__ __attribute__((aligned(16))) float s_g[1280 * 2];
@@ -424,9 +432,19 @@ __global__ __launch_bounds__(256) void layernorm_rowgroup_kernel(const T* __rest
         *reinterpret_cast<float4*>(bb + 4 * t) = *reinterpret_cast<const float4*>(s_b + c0 + 4 * t);
       }
       Vec16<T> o;
+      float ff[EPC];
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) o.e[e] = from_f32<T>((to_f32<T>(v[i].e[e]) - mean) * rstd * g[e] + bb[e]);
-      *reinterpret_cast<uint4*>(y + row * ldy + c0) = o.u;
+      for (int e = 0; e < EPC; ++e) {
+        ff[e] = (to_f32<T>(v[i].e[e]) - mean) * rstd * g[e] + bb[e];
+        o.e[e] = from_f32<T>(ff[e]);
+      }
+      if (fp8_mul != 0.f) {   // e4m3 output (ldy in bytes)
+        unsigned char* y8 = reinterpret_cast<unsigned char*>(y) + row * ldy + c0;
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) *reinterpret_cast<unsigned*>(y8 + e) = gn_pack4_e4m3(ff[e], ff[e + 1], ff[e + 2], ff[e + 3], fp8_mul);
+      } else {
+        *reinterpret_cast<uint4*>(y + row * ldy + c0) = o.u;
+      }
     }
 }
 
@@ -491,8 +509,9 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
 
 template <typename T>
 int af_launch_layernorm(const void* x, int ldx, long rows, int Cn, const float* gamma, const float* beta,
-                        float eps, void* y, int ldy, hipStream_t stream) {
+                        float eps, void* y, int ldy, hipStream_t stream, float fp8_mul) {
   constexpr int EPC = 16 / sizeof(T);
+  if (fp8_mul != 0.f && sizeof(T) != 2) { af_set_error_msg("layernorm: fp8 output needs the bf16 storage mode"); return -1; }
   if (Cn % EPC != 0 || Cn / EPC > 64 * LN_MAXV || ldx % EPC != 0 || ldy % EPC != 0) {
     af_set_error_msg("layernorm: unsupported C=%d", Cn);
     return -1;
@@ -505,13 +524,13 @@ int af_launch_layernorm(const void* x, int ldx, long rows, int Cn, const float* 
   // (few rows of many vectors -- [4096, 1280] -- fill the chip better with one wave per row: measured 10 vs 19 us)
   if (NV % RL == 0 && NV / RL <= 10 && Cn <= 1280 && Cn % 4 == 0 && rows / RPB >= 256) {
     hipLaunchKernelGGL((layernorm_rowgroup_kernel<T, RL>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, stream,
-                       reinterpret_cast<const T*>(x), ldx, rows, Cn, gamma, beta, eps, reinterpret_cast<T*>(y), ldy);
+                       reinterpret_cast<const T*>(x), ldx, rows, Cn, gamma, beta, eps, reinterpret_cast<T*>(y), ldy, fp8_mul);
     HIP_CHECK_RET(hipGetLastError());
     return 0;
   }
   hipLaunchKernelGGL((layernorm_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream,
                      reinterpret_cast<const T*>(x), ldx, rows, Cn, gamma, beta, eps,
-                     reinterpret_cast<T*>(y), ldy);
+                     reinterpret_cast<T*>(y), ldy, fp8_mul);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -521,6 +540,6 @@ template int af_launch_groupnorm<bf16>(const void*, long, int, int, int, int, co
 template int af_launch_groupnorm<float>(const void*, long, int, int, int, int, const float*, const float*, float,
                                         int, void*, long, int, void*, hipStream_t, float);
 template int af_launch_layernorm<bf16>(const void*, int, long, int, const float*, const float*, float, void*, int,
-                                       hipStream_t);
+                                       hipStream_t, float);
 template int af_launch_layernorm<float>(const void*, int, long, int, const float*, const float*, float, void*,
-                                        int, hipStream_t);
+                                        int, hipStream_t, float);

@@ -158,6 +158,17 @@ int af_op_groupnorm_fp8(const float* x_dev, const float* gamma_dev, const float*
   return 0;
 }
 
+// LayerNorm with the e4m3 output the fp8 q / k / v projection reads: y8_dev [rows][C] bytes of result * 2^act_shift
+int af_op_layernorm_fp8(const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, unsigned char* y8_dev,
+                        int64_t rows, int C, int act_shift, void* stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Tmp tmp;
+  OP_ALLOC(xn, (size_t)rows * C * 2, false);
+  OP_TRY(af_launch_cast_f32<bf16>(x_dev, xn, rows * C, s));
+  OP_TRY(af_launch_layernorm<bf16>(xn, C, rows, C, gamma_dev, beta_dev, eps, y8_dev, C, s, (float)(1 << act_shift)));
+  return 0;
+}
+
 int af_op_linear(int dtype, const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev,
                  float* y_dev, int64_t M, int K, int N, int geglu, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -76,6 +76,18 @@ def group_norm_fp8(x, weight, bias, eps=1e-5, silu=False, act_shift=FP8_ACT_SHIF
     return y
 
 
+def layer_norm_fp8(x, weight, bias, eps=1e-5, act_shift=FP8_ACT_SHIFT):
+    """LayerNorm over the last dim written as e4m3 bytes of result * 2^act_shift: uint8, same shape as x."""
+    lib = _lib.load()
+    x = _dev_f32(x)
+    Cn = x.shape[-1]
+    rows = x.numel() // Cn
+    y = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    check(lib.af_op_layernorm_fp8(ptr(x), ptr(_dev_f32(weight)), ptr(_dev_f32(bias)), eps, ptr(y), rows, Cn, act_shift,
+                                  stream_ptr()), "af_op_layernorm_fp8")
+    return y
+
+
 def linear(x, weight, bias=None, residual=None, geglu=False, dtype="bf16"):
     """F.linear over the last dim; geglu=True applies GEGLU (attention.py:32-45) to the projection."""
     lib = _lib.load()

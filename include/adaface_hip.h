@@ -202,7 +202,8 @@ int af_op_groupnorm(int dtype, const float* x_dev, const float* gamma_dev, const
  * reference has no fp8 path: torch autocast fp16 at most, scripts/stable_txt2img.py:711).  af_set_fp8(h, 1) on a bf16
  * handle: GroupNorm + SiLU (openaimodel.py:259-263, in_layers / out_layers) writes e4m3 and the 3x3 convolutions that read
  * it multiply on v_mfma_scale_f32_16x16x128_f8f6f4 with power-of-two scales (per output channel for the weights, 2^3 for
- * the activations); everything else stays bf16.  Tolerance: tests/test_fp8_gpu.py. */
+ * the activations); likewise norm1 -> to_q / to_k / to_v of every BasicTransformerBlock's self-attention
+ * (attention.py:195-196, 275-285); everything else stays bf16.  Tolerance: tests/test_fp8_gpu.py. */
 int af_set_fp8(af_handle* h, int on);
 int64_t af_fp8_gemm_launches(void); /* launches on the fp8 kernel since af_gemm_plan_counts_reset */
 int af_op_conv2d_fp8(const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev, float* y_dev,
@@ -210,6 +211,8 @@ int af_op_conv2d_fp8(const float* x_dev, const float* w_dev, const float* bias_d
                      void* stream);
 int af_op_groupnorm_fp8(const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, int silu,
                         unsigned char* y8_dev, int B, int C, int H, int W, int act_shift, void* stream);
+int af_op_layernorm_fp8(const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, unsigned char* y8_dev,
+                        int64_t rows, int C, int act_shift, void* stream);
 /* F.layer_norm over the last dim of [rows, C]. */
 int af_op_layernorm(int dtype, const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps,
                     float* y_dev, int64_t rows, int C, void* stream);

@@ -6,6 +6,7 @@ The reference has no fp8 path, so there is nothing of its own to compare an fp8 
       (5e-3 of the output scale), over 3x3 / 1x1 / strided / upsampled / split-K shapes and channel counts that are
       multiples of 64 but not of 128 (a K tile straddling two filter taps);
   (2) the PRODUCER: GroupNorm + SiLU written as e4m3 within half an e4m3 step of the f32 result;
+  (2b) LayerNorm written as e4m3 (the producer of the fp8 q / k / v projection) to the same bound;
   (3) the MODEL: full SD-1.5 UNet at the benchmark batch in fp8 mode against its own bf16 and f32-mode forwards.  Stated
       tolerance of the fp8 mode: max-abs eps deviation <= 8e-2 of max|eps| per forward against f32 (measured: see
       gpurun_out/parity_report.txt); the bf16 mode's bar is 3e-2.
@@ -117,9 +118,27 @@ def test_groupnorm_fp8_output(gpu, report, B, C, H, W, silu):
     assert excess <= 0.0, excess
 
 
+@pytest.mark.parametrize("rows,C", [(4096, 320), (1024, 640), (256, 1280), (130, 1280)])
+def test_layernorm_fp8_output(gpu, report, rows, C):
+    """Both LayerNorm kernels (row-group / wave-per-row) with the e4m3 output, same bound as the GroupNorm test."""
+    from adaface_amd import ops
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 2.0 + 0.3).to(torch.bfloat16).float()
+    w = torch.randn(C, generator=g) * 0.3 + 1.0
+    b = torch.randn(C, generator=g) * 0.2
+    ref = F.layer_norm(x, (C,), w, b, 1e-5).clamp(-448.0 / 8, 448.0 / 8)
+    got = ops.layer_norm_fp8(x.to(gpu), w.to(gpu), b.to(gpu)).cpu().view(torch.float8_e4m3fn).float() / 2.0 ** ACT_SHIFT
+    bound = ref.abs() * (2.0 ** -4) * 1.02 + 2.0 ** -10 / 8 + 2e-4
+    excess = ((got - ref).abs() - bound).max().item()
+    report(f"layernorm->e4m3 [{rows},{C}]: worst excess over half an e4m3 step", max(excess, 0.0), 1.0, 0.0)
+    assert torch.isfinite(got).all() and excess <= 0.0, excess
+
+
 def test_sd15_unet_fp8_mode(gpu, report):
     """Full SD-1.5 UNet at the benchmark batch (Bf = 16): fp8 mode against the bf16 and f32-mode forwards of the same
-    weights and inputs; asserts that the ResBlock convolutions really ran on the fp8 kernel (44 launches: 22 ResBlocks)."""
+    weights and inputs; asserts that the ResBlock convolutions and the self-attention q / k / v projections really ran on the
+    fp8 kernel (44 + 15 launches: 22 ResBlocks, 16 transformer blocks of which the middle block's -- 1024 rows at 8x8 -- does
+    not fill half of the chip with 256-row tiles and stays on the bf16 path, as the planner's fill rule says)."""
     import sys
     from pathlib import Path
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -144,7 +163,7 @@ def test_sd15_unet_fp8_mode(gpu, report):
             _lib.plan_counts(reset=True)
             eps["fp8"] = eng.unet_forward(x, t)
             pc = _lib.plan_counts(reset=True)
-            assert pc["fp8"] == 44, pc
+            assert pc["fp8"] == 59, pc
             eng.set_fp8(False)
             again = eng.unet_forward(x, t)
             assert _lib.plan_counts(reset=True)["fp8"] == 0 and torch.equal(again, eps["bf16"])   # the switch is clean
