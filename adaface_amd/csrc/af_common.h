@@ -82,6 +82,7 @@ struct AfKnobs {
   int gn_fold;              // AF_GN_FOLD              0 = separate GroupNorm finalize pass
   int conv_tap_inner;       // AF_CONV_TAP_INNER       0 = ping-pong convs walk K tap-outermost (the round-1 order)
   int ln_fuse;              // AF_LN_FUSE              0 = stand-alone LayerNorm kernels in front of the transformer GEMMs
+  int conv_halo8;           // AF_CONV_HALO8           0 = 3x3 / stride-1 convs stay on the gathering eight-wave kernel (no LDS halo)
   int conv_fast_taps;       // AF_CONV_FAST_TAPS       0 = ping-pong convs recompute every tap's bounds check in the staging phase
   int pp_sched;             // AF_PP_SCHED             eight-wave kernel: 0 = round-1 compute phase (two K halves, a full LDS drain
                             //                         after each), 1 = block-ordered compute phase, 2 = merged (no staging phase)

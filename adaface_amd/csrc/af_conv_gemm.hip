@@ -488,6 +488,232 @@ __device__ __forceinline__ void pp_wait_lgkm0() {
   __builtin_amdgcn_sched_barrier(0);   // hipcc hoists register-only MFMAs over an asm wait without this
 }
 
+// Epilogue of the eight-wave kernels (shared by conv_gemm_pp_kernel and conv3x3_halo8_kernel): bias / LayerNorm / GEGLU on
+// the accumulators, then either straight from the registers or through an fp32 LDS tile in two 128-row passes.
+// Accumulator layout: wave (g, wq) holds rows m0 + wq * 64 + j * 16 + (lane & 15), columns n0 + g * HN + i * 16 +
+// 4 * (lane >> 4) + e in acc[i][j][e].
+template <int BN, int LNMODE>
+__device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc)[PpCfg<BN>::NI][PpCfg<BN>::MI],
+                                            float4 (&bias_r)[PpCfg<BN>::NI], float4 (&ln_cs)[LNMODE == 1 ? PpCfg<BN>::NI : 1],
+                                            float (&ln_mu)[LNMODE == 1 ? PpCfg<BN>::MI : 1],
+                                            float (&ln_rs)[LNMODE == 1 ? PpCfg<BN>::MI : 1], char* smem, int tid, int lane,
+                                            int g, int wq, int m0, int n0, int tn, int zk) {
+  using C = PpCfg<BN>;
+  typedef bf16 T;
+  constexpr int NI = C::NI, MI = C::MI;
+  const int cl = 4 * (lane >> 4);
+  const int HoWo = p.Ho * p.Wo;
+  // ------------------------------- epilogue -------------------------------
+  // GEGLU is evaluated in registers by all eight waves first (value block 2k, gate block 2k+1 of the same lane);
+  // then two passes of 128 rows: waves with (wq >> 1) == pass put their accumulators into an fp32 LDS tile and all
+  // 512 threads walk it in 8-column vectors (a wave covers whole contiguous rows).  Every load of a pass (LDS tile,
+  // time-embedding row, residual) is issued before the first store so their latencies overlap.
+  float* et = reinterpret_cast<float*>(smem);
+  const bool geglu = p.epilogue == AF_EPI_GEGLU;
+  if (geglu) {
+    if constexpr ((NI & 1) == 0) {
+      // packed weight rows [32k, 32k+16) are "value", [32k+16, 32k+32) "gate" (bias packed alike)
+#pragma unroll
+      for (int k2 = 0; k2 < NI / 2; ++k2) {
+        const float* bvp = reinterpret_cast<const float*>(&bias_r[2 * k2]);
+        const float* bgp = reinterpret_cast<const float*>(&bias_r[2 * k2 + 1]);
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float val, gat;
+            if constexpr (LNMODE == 1) {
+              val = (acc[2 * k2][j][e] - ln_mu[j] * reinterpret_cast<const float*>(&ln_cs[2 * k2])[e]) * ln_rs[j] + bvp[e];
+              gat = (acc[2 * k2 + 1][j][e] - ln_mu[j] * reinterpret_cast<const float*>(&ln_cs[2 * k2 + 1])[e]) * ln_rs[j] + bgp[e];
+            } else {
+              val = acc[2 * k2][j][e] * p.alpha + bvp[e];
+              gat = acc[2 * k2 + 1][j][e] * p.alpha + bgp[e];
+            }
+            acc[k2][j][e] = val * gelu_bf16out_f(gat);   // block k2 <= 2 k2: already consumed
+          }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float* bp = reinterpret_cast<const float*>(&bias_r[i]);
+#pragma unroll
+      for (int j = 0; j < MI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (LNMODE == 1)
+            acc[i][j][e] = (acc[i][j][e] - ln_mu[j] * reinterpret_cast<const float*>(&ln_cs[i])[e]) * ln_rs[j] + bp[e];
+          else
+            acc[i][j][e] = acc[i][j][e] * p.alpha + bp[e];
+        }
+    }
+  }
+  const int BNo = geglu ? BN / 2 : BN;              // columns of the staged tile
+  const int HNo = geglu ? C::HN / 2 : C::HN;        // ... per wave group
+  const int tpr = BNo >> 3;
+  const int ncol0 = geglu ? (n0 >> 1) : n0;
+  const int Nvalid = geglu ? (p.N >> 1) : p.N;
+  T* __restrict__ out = reinterpret_cast<T*>(p.out);
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+  const T* __restrict__ rowb = reinterpret_cast<const T*>(p.rowbias);
+  float* slab = p.splitk > 1 ? reinterpret_cast<float*>(p.ws) + (long)zk * p.M * p.N : nullptr;
+  if (LNMODE == 2 || p.pp_epilogue == 2 || (p.pp_epilogue == 0 && (geglu || slab))) {
+    // Direct epilogue: every lane stores its 4 consecutive output channels of a pixel straight from the accumulator
+    // (8-byte stores, four lanes covering a 32-byte run of the row; fp32 split-K slabs: 16-byte stores).  No LDS pass,
+    // no workgroup barriers; the time-bias / residual quads of a row group are fetched before its first store.
+    // Measured against the two-pass LDS transposition below: GEGLU -4...-6 %, split-K slabs -2...-5 %, everything else
+    // within +-1 %, so it is the default for those two and AF_PP_DIRECT = 0 / 1 forces either.
+    const int nblk = geglu ? NI / 2 : NI;
+    const int cbase = ncol0 + g * HNo + cl;
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int m = m0 + wq * 64 + j * 16 + (lane & 15);
+      if constexpr (LNMODE == 2) {
+        // statistics producer: every lane takes part in the row reduction, rows >= M contribute nothing and store nothing
+        const bool mok = m < p.M;
+        Quad<T> rq[NI], bq[NI];
+        if (rowb && mok) {
+          const T* rp = rowb + (long)(p.howo_shift >= 0 ? m >> p.howo_shift : m / HoWo) * p.ldrb + cbase;
+#pragma unroll
+          for (int i = 0; i < NI; ++i) bq[i].load(rp + i * 16);
+        }
+        if (res && mok) {
+          const T* rp = res + (long)m * p.ldr + cbase;
+#pragma unroll
+          for (int i = 0; i < NI; ++i) rq[i].load(rp + i * 16);
+        }
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          Quad<T> o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][j][e];
+            if (rowb && mok) v += to_f32<T>(bq[i].e[e]);
+            if (res && mok) v += to_f32<T>(rq[i].e[e]);
+            o.e[e] = from_f32<T>(v);
+            const float vr = to_f32<T>(o.e[e]);   // the value the consumer will read
+            ps += vr;
+            pq += vr * vr;
+          }
+          if (mok) o.store(out + (long)m * p.ldo + cbase + i * 16);
+        }
+        ps += __shfl_xor(ps, 16, 64); pq += __shfl_xor(pq, 16, 64);
+        ps += __shfl_xor(ps, 32, 64); pq += __shfl_xor(pq, 32, 64);
+        if (mok && (lane >> 4) == 0)
+          *reinterpret_cast<float2*>(p.ln_stats_out + ((long)(tn * 2 + g) * p.M + m) * 2) = float2{ps, pq};
+        continue;
+      }
+      if (m >= p.M) continue;
+      if (slab) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          if (i < nblk) *reinterpret_cast<f32x4*>(slab + (long)m * p.N + cbase + i * 16) = acc[i][j];
+        continue;
+      }
+      Quad<T> rq[NI], bq[NI];
+      if (rowb) {
+        const T* rp = rowb + (long)(p.howo_shift >= 0 ? m >> p.howo_shift : m / HoWo) * p.ldrb + cbase;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) if (i < nblk) bq[i].load(rp + i * 16);
+      }
+      if (res) {
+        const T* rp = res + (long)m * p.ldr + cbase;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) if (i < nblk) rq[i].load(rp + i * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if (i >= nblk) continue;
+        Quad<T> o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][j][e];
+          if (rowb) v += to_f32<T>(bq[i].e[e]);
+          if (res) v += to_f32<T>(rq[i].e[e]);
+          o.e[e] = from_f32<T>(v);
+        }
+        o.store(out + (long)m * p.ldo + cbase + i * 16);
+      }
+    }
+    return;
+  }
+  constexpr int ITEMS = BN / 32;                    // 8-column vectors per thread and pass (GEGLU: half of them)
+  const int nitems = geglu ? ITEMS / 2 : ITEMS;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass) __syncthreads();
+    if ((wq >> 1) == pass) {
+      const int rbase = (wq & 1) * 64 + (lane & 15);
+      const int nblk = geglu ? NI / 2 : NI;
+#pragma unroll
+      for (int j = 0; j < MI; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          if (i < nblk)
+            *reinterpret_cast<f32x4*>(et + (rbase + j * 16) * C::EPI_LD + g * HNo + i * 16 + cl) = acc[i][j];
+    }
+    __syncthreads();
+    // ---- gather phase: everything this thread needs for its ITEMS vectors ----
+    float v[ITEMS][8];
+    int im[ITEMS], in_[ITEMS];
+    Quad<T> rq[ITEMS][2], bq[ITEMS][2];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * 512;
+      const int row = geglu ? idx / (BN / 16) : idx / (BN / 8);   // constant divisors: no runtime integer division
+      const int c8 = (idx - row * tpr) * 8;
+      const int m = m0 + pass * 128 + row, n = ncol0 + c8;
+      const bool ok = it < nitems && m < p.M && n < Nvalid;
+      im[it] = ok ? m : -1;
+      in_[it] = n;
+      if (!ok) continue;
+      const float4 a = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8);
+      const float4 b4 = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8 + 4);
+      v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
+      v[it][4] = b4.x; v[it][5] = b4.y; v[it][6] = b4.z; v[it][7] = b4.w;
+      if (slab) continue;
+      if (rowb) {
+        const T* rp = rowb + (long)(p.howo_shift >= 0 ? m >> p.howo_shift : m / HoWo) * p.ldrb + n;
+        bq[it][0].load(rp);
+        bq[it][1].load(rp + 4);
+      }
+      if (res) {
+        const T* rp = res + (long)m * p.ldr + n;
+        rq[it][0].load(rp);
+        rq[it][1].load(rp + 4);
+      }
+    }
+    // ---- combine + store ----
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int m = im[it], n = in_[it];
+      if (m < 0) continue;
+      if (slab) {
+        *reinterpret_cast<float4*>(slab + (long)m * p.N + n) = float4{v[it][0], v[it][1], v[it][2], v[it][3]};
+        *reinterpret_cast<float4*>(slab + (long)m * p.N + n + 4) = float4{v[it][4], v[it][5], v[it][6], v[it][7]};
+        continue;
+      }
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq) {
+        float* vv = v[it] + 4 * hq;
+        if (rowb) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] += to_f32<T>(bq[it][hq].e[e]);
+        }
+        if (res) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] += to_f32<T>(rq[it][hq].e[e]);
+        }
+        Quad<T> o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.e[e] = from_f32<T>(vv[e]);
+        o.store(out + (long)m * p.ldo + n + 4 * hq);
+      }
+    }
+  }
+}
+
 template <int N> __device__ __forceinline__ void pp_wait_lgkm() {   // counted: LDS reads return in order
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
@@ -1020,215 +1246,272 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
   if constexpr (!MG) { if (g == 0) __builtin_amdgcn_s_barrier(); }
   if constexpr (NS) load_bias();
 
-  // ------------------------------- epilogue -------------------------------
-  // GEGLU is evaluated in registers by all eight waves first (value block 2k, gate block 2k+1 of the same lane);
-  // then two passes of 128 rows: waves with (wq >> 1) == pass put their accumulators into an fp32 LDS tile and all
-  // 512 threads walk it in 8-column vectors (a wave covers whole contiguous rows).  Every load of a pass (LDS tile,
-  // time-embedding row, residual) is issued before the first store so their latencies overlap.
-  float* et = reinterpret_cast<float*>(smem);
-  const bool geglu = p.epilogue == AF_EPI_GEGLU;
-  if (geglu) {
-    if constexpr ((NI & 1) == 0) {
-      // packed weight rows [32k, 32k+16) are "value", [32k+16, 32k+32) "gate" (bias packed alike)
+  pp_epilogue<BN, LNMODE>(p, acc, bias_r, ln_cs, ln_mu, ln_rs, smem, tid, lane, g, wq, m0, n0, tn, zk);
+}
+
+// ---------------------------------------------------------------------------
+// Eight-wave 3x3 / stride 1 / pad 1 convolution with an LDS-resident input HALO (bf16, 256 x 160 tile, merged schedule).
+//
+// The implicit-GEMM kernel above stages every input pixel of its tile nine times (once per filter tap): 32 of the 52
+// LDS-DMA pieces of a K step are activations, and it is the number of those pieces a wave has to issue between its MFMAs,
+// not the MFMA rate, that sets the step time (timing ablations: scripts/lab/ablate_conv.sh).  Here a workgroup's 256
+// output pixels are R = 256 / Wo whole rows of one image; for each 64-channel chunk their (R + 2) x (Wo + 2) input halo
+// is staged ONCE (<= 50 pieces, spread over the nine tap steps of the PREVIOUS chunk: at most one per wave and step) and
+// the nine taps read their MFMA operand from it at shifted pixel addresses; only the 160 x 64 weight tile streams per
+// step (20 pieces).  A wave issues 2-4 pieces per step instead of 6-7 and the L2 -> LDS traffic halves.
+//   LDS (all 160 KiB): two halo buffers of 400 pixels x 128 B (chunk c / chunk c + 1) + three weight slots of 20 KiB.
+//   Halo pixel hp = hy * (Wo + 2) + hx holds input pixel (row0 - 1 + hy, hx - 1); its 16-byte chunk c sits in slot
+//   c ^ (hp & 7) (the swizzle of the other kernels: 16 consecutive pixels of a row are conflict-free for ds_read_b128).
+//   The per-lane source address of every halo piece is computed once (validity included: pixels outside the image are
+//   out-of-range addresses = zeros); per chunk only the scalar channel offset changes.
+//   Output rows, accumulators and the epilogue are those of conv_gemm_pp_kernel (the tile is 256 consecutive pixels in
+//   (b, y, x) raster order), K is walked (channel chunk, tap) and a K slice (split-K) is a whole number of chunks.
+// ---------------------------------------------------------------------------
+struct Halo8Cfg {
+  static constexpr int BN = 160;
+  static constexpr int HPIX = 400, HBUF = HPIX * 128, WBYTES = BN * 128;
+  static constexpr int W_BASE = 2 * HBUF, LDS_BYTES = 2 * HBUF + 3 * WBYTES;   // 163840 = the whole LDS
+  static constexpr int NHQ = 7;   // halo pieces per wave and chunk, at most (50 pieces over 8 waves)
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+__global__ __launch_bounds__(512) void conv3x3_halo8_kernel(const ConvGemmParams p) {
+  using C = PpCfg<160>;
+  using H = Halo8Cfg;
+  typedef bf16 T;
+  constexpr int BN = 160, NI = C::NI, MI = C::MI, NHQ = H::NHQ;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wid >> 2, wq = wid & 3;
+  const int ntm = p.M / 256, ntn = p.N / BN;
+  int tm, tn;
+  tile_coords(blockIdx.x, gridDim.x, ntm, ntn, p.group_m, tm, tn);
+  const int m0 = tm * 256, n0 = tn * BN;
+  const int zk = blockIdx.z;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(reinterpret_cast<const T*>(p.src)), 0, (int)0xFFFFFFF0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(reinterpret_cast<const T*>(p.W)), 0, (int)0xFFFFFFF0u, 0x00020000);
+
+  // K range: steps s = (chunk, tap), nine per chunk; a slice is a whole number of chunks (the launcher checks)
+  const int KT_all = p.K / 64;
+  const int kt_per = (KT_all + p.splitk - 1) / p.splitk;
+  const int kt_begin = zk * kt_per;
+  const int KT = min(KT_all, kt_begin + kt_per) - kt_begin;
+  const int chunk0 = kt_begin / 9;
+
+  // ---- geometry: the tile is R rows of image b starting at row y0 ----
+  const int Wo = p.Wo, HW = Wo + 2, wsh = p.wo_shift;
+  const int R = 256 >> wsh;
+  const int HP = (R + 2) * HW;                  // halo pixels (<= 400)
+  const int img = m0 >> p.howo_shift;
+  const int y0 = (m0 & (p.Ho * Wo - 1)) >> wsh;
+  const int srow = lane >> 3;
+  const unsigned dchunk = (unsigned)((lane & 7) ^ srow);
+  const unsigned ldcb = (unsigned)p.ldc * 2u;
+
+  // halo pieces of this wave: piece wid + 8 q covers halo pixels 8 * piece .. + 7 (lane >> 3 = pixel, lane & 7 = slot)
+  unsigned h_off[NHQ];
+  const int nhq = (H::HPIX / 8 - 1 - wid) / 8 + 1;   // pieces that exist for this wave in a 400-pixel buffer (7 or 6)
 #pragma unroll
-      for (int k2 = 0; k2 < NI / 2; ++k2) {
-        const float* bvp = reinterpret_cast<const float*>(&bias_r[2 * k2]);
-        const float* bgp = reinterpret_cast<const float*>(&bias_r[2 * k2 + 1]);
-#pragma unroll
-        for (int j = 0; j < MI; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float val, gat;
-            if constexpr (LNMODE == 1) {
-              val = (acc[2 * k2][j][e] - ln_mu[j] * reinterpret_cast<const float*>(&ln_cs[2 * k2])[e]) * ln_rs[j] + bvp[e];
-              gat = (acc[2 * k2 + 1][j][e] - ln_mu[j] * reinterpret_cast<const float*>(&ln_cs[2 * k2 + 1])[e]) * ln_rs[j] + bgp[e];
-            } else {
-              val = acc[2 * k2][j][e] * p.alpha + bvp[e];
-              gat = acc[2 * k2 + 1][j][e] * p.alpha + bgp[e];
-            }
-            acc[k2][j][e] = val * gelu_bf16out_f(gat);   // block k2 <= 2 k2: already consumed
-          }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const float* bp = reinterpret_cast<const float*>(&bias_r[i]);
-#pragma unroll
-      for (int j = 0; j < MI; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if constexpr (LNMODE == 1)
-            acc[i][j][e] = (acc[i][j][e] - ln_mu[j] * reinterpret_cast<const float*>(&ln_cs[i])[e]) * ln_rs[j] + bp[e];
-          else
-            acc[i][j][e] = acc[i][j][e] * p.alpha + bp[e];
-        }
-    }
+  for (int q = 0; q < NHQ; ++q) {
+    const int hp = (wid + 8 * q) * 8 + srow;
+    const int hy = hp / HW, hx = hp - hy * HW;
+    const int iy = y0 - 1 + hy, ix = hx - 1;
+    const bool ok = hp < HP && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+    h_off[q] = ok ? (unsigned)((long)img * p.src_batch_stride * 2) + (unsigned)(iy * p.Ws + ix) * ldcb + dchunk * 16u : 0xFFFFFFFFu;
   }
-  const int BNo = geglu ? BN / 2 : BN;              // columns of the staged tile
-  const int HNo = geglu ? C::HN / 2 : C::HN;        // ... per wave group
-  const int tpr = BNo >> 3;
-  const int ncol0 = geglu ? (n0 >> 1) : n0;
-  const int Nvalid = geglu ? (p.N >> 1) : p.N;
-  T* __restrict__ out = reinterpret_cast<T*>(p.out);
-  const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
-  const T* __restrict__ rowb = reinterpret_cast<const T*>(p.rowbias);
-  float* slab = p.splitk > 1 ? reinterpret_cast<float*>(p.ws) + (long)zk * p.M * p.N : nullptr;
-  if (LNMODE == 2 || p.pp_epilogue == 2 || (p.pp_epilogue == 0 && (geglu || slab))) {
-    // Direct epilogue: every lane stores its 4 consecutive output channels of a pixel straight from the accumulator
-    // (8-byte stores, four lanes covering a 32-byte run of the row; fp32 split-K slabs: 16-byte stores).  No LDS pass,
-    // no workgroup barriers; the time-bias / residual quads of a row group are fetched before its first store.
-    // Measured against the two-pass LDS transposition below: GEGLU -4...-6 %, split-K slabs -2...-5 %, everything else
-    // within +-1 %, so it is the default for those two and AF_PP_DIRECT = 0 / 1 forces either.
-    const int nblk = geglu ? NI / 2 : NI;
-    const int cbase = ncol0 + g * HNo + cl;
+  // weight pieces of this wave: piece wid + 8 q, q < 3 (waves 0-3) or 2 (waves 4-7)
+  unsigned w_off[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int n = n0 + (wid + 8 * q) * 8 + srow;
+    w_off[q] = (n < p.Wrows && (wid + 8 * q) < BN / 8) ? (unsigned)((long)n * p.ldw * 2) + dchunk * 16u : 0xFFFFFFFFu;
+  }
+  const int nwq = g == 0 ? 3 : 2;
+
+  // ---- fragment addressing ----
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) char*)smem);
+  const unsigned fch0 = (unsigned)((lane >> 4) ^ (lane & 7)) * 16u;
+  const unsigned fch1 = (unsigned)(((lane >> 4) + 4) ^ (lane & 7)) * 16u;
+  const unsigned w_base = (unsigned)((g * C::HN + (lane & 15)) * 128);
+  // halo pixel of tap (0, 0) for this lane's output pixel of block j: tile pixel t = wq * 64 + j * 16 + (lane & 15)
+  int xhp[MI];
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const int t = wq * 64 + j * 16 + (lane & 15);
+    xhp[j] = (t >> wsh) * HW + (t & (Wo - 1));
+  }
+  const unsigned qsel = (unsigned)(lane >> 4);
+
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  pp_u32x4 w8[NI][2], xa8[MI][2], xb8[MI][2];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) w8[i][0] = w8[i][1] = pp_u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int j = 0; j < MI; ++j) xa8[j][0] = xa8[j][1] = xb8[j][0] = xb8[j][1] = pp_u32x4{0u, 0u, 0u, 0u};
+  auto mfma2 = [&](f32x4& c, const pp_u32x4 (&wv)[2], const pp_u32x4 (&xv)[2]) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[0]), __builtin_bit_cast(bf16x8, xv[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[1]), __builtin_bit_cast(bf16x8, xv[1]), c, 0, 0, 0);
+    asm volatile("" : "+v"(c));
+  };
+  auto wait_block = [&](auto nc, pp_u32x4 (&blk)[2]) {
+    constexpr int n = decltype(nc)::value;
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(blk[0]), "+v"(blk[1]) : "n"(n) : "memory");
+  };
+
+  // ---- staging (everything by value: see KWalk in conv_gemm_pp_kernel) ----
+  struct Step { int tap, chunk; };             // the step being STAGED (weights) / the chunk whose halo is being staged
+  auto stage_w = [&](auto qc, int wslot, Step st, int live) {
+    constexpr int q = decltype(qc)::value;
+    const unsigned k0b = (unsigned)(st.tap * p.Cin + st.chunk * 64) * 2u;
+    const unsigned a = live ? w_off[q] : 0xFFFFFFFFu;
+    lds_dma16(rs_w, smem + H::W_BASE + wslot * H::WBYTES + (wid + 8 * q) * 1024, a, k0b);
+  };
+  auto stage_h = [&](auto qc, int hbuf, int chunk, int live) {
+    constexpr int q = decltype(qc)::value;
+    const unsigned a = live ? h_off[q] : 0xFFFFFFFFu;
+    lds_dma16(rs_x, smem + hbuf * H::HBUF + (wid + 8 * q) * 1024, a, (unsigned)chunk * 128u);
+  };
+  const int nchunks_all = p.Cin >> 6;
+  const int step_end = kt_begin + KT;          // first step (global index) that does not exist
+
+  // one K step: compute (chunk, tap) from halo buffer hb and weight slot ws while staging the weights of step + 2 into
+  // slot ws2 and, during the first nhq taps, one halo piece of chunk + 1 into the other halo buffer
+  auto step = [&](int s_glob, int tap, int hb, int ws, int ws2, pp_u32x4 (&xc)[MI][2], pp_u32x4 (&xp)[MI][2]) {
+    constexpr int NB = NI + MI;
+    const int chunk = s_glob / 9;               // (scalar division by a constant)
+    // what this step stages
+    const int s2 = s_glob + 2;
+    Step st2;
+    st2.chunk = s2 / 9;
+    st2.tap = s2 - st2.chunk * 9;
+    const int live_w = s2 < step_end ? 1 : 0;
+    const int live_h = ((chunk + 1) * 9 < step_end && chunk + 1 < nchunks_all) ? 1 : 0;
+    // operand addresses of this tap
+    const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+    const int tapoff = ky * HW + kx;
+    unsigned xa0[MI];
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-      const int m = m0 + wq * 64 + j * 16 + (lane & 15);
-      if constexpr (LNMODE == 2) {
-        // statistics producer: every lane takes part in the row reduction, rows >= M contribute nothing and store nothing
-        const bool mok = m < p.M;
-        Quad<T> rq[NI], bq[NI];
-        if (rowb && mok) {
-          const T* rp = rowb + (long)(p.howo_shift >= 0 ? m >> p.howo_shift : m / HoWo) * p.ldrb + cbase;
-#pragma unroll
-          for (int i = 0; i < NI; ++i) bq[i].load(rp + i * 16);
+      const unsigned hp = (unsigned)(xhp[j] + tapoff);
+      xa0[j] = lds0 + (unsigned)(hb * H::HBUF) + (hp << 7) + (((qsel ^ hp) & 7u) << 4);
+    }
+    const unsigned wb0 = lds0 + (unsigned)(H::W_BASE + ws * H::WBYTES) + w_base + fch0;
+    const unsigned wb1 = lds0 + (unsigned)(H::W_BASE + ws * H::WBYTES) + w_base + fch1;
+    auto rd_block = [&](auto bc) {
+      constexpr int bi = decltype(bc)::value;
+      if constexpr (bi == 0) {
+        w8[0][0] = pp_lds_read128<0>(wb0);
+        w8[0][1] = pp_lds_read128<0>(wb1);
+      } else if constexpr (bi <= MI) {
+        xc[bi - 1][0] = pp_lds_read128<0>(xa0[bi - 1]);
+        xc[bi - 1][1] = pp_lds_read128<0>(xa0[bi - 1] ^ 64u);
+      } else {
+        w8[bi - MI][0] = pp_lds_read128<(bi - MI) * 2048>(wb0);
+        w8[bi - MI][1] = pp_lds_read128<(bi - MI) * 2048>(wb1);
+      }
+    };
+    rd_block(std::integral_constant<int, 0>{});
+    rd_block(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    pp_static_for<0, MI * NI>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      if constexpr (m < MI) {
+        mfma2(acc[NI - 1][m], w8[NI - 1], xp[m]);          // held back from the previous step
+      } else {
+        constexpr int i = (m - MI) / MI, j = (m - MI) % MI;
+        constexpr int issued = (2 + m) < NB ? (2 + m) : NB;
+        constexpr int need = i == 0 ? 1 + j : (j == 0 ? MI + i : -1);
+        if constexpr (need >= 0) {
+          std::integral_constant<int, 2 * (issued - need - 1)> cnt;
+          if constexpr (i == 0) wait_block(cnt, xc[j]); else wait_block(cnt, w8[i]);
+          if constexpr (i == 0 && j == 0) wait_block(cnt, w8[0]);
         }
-        if (res && mok) {
-          const T* rp = res + (long)m * p.ldr + cbase;
-#pragma unroll
-          for (int i = 0; i < NI; ++i) rq[i].load(rp + i * 16);
-        }
-        float ps = 0.f, pq = 0.f;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          Quad<T> o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = acc[i][j][e];
-            if (rowb && mok) v += to_f32<T>(bq[i].e[e]);
-            if (res && mok) v += to_f32<T>(rq[i].e[e]);
-            o.e[e] = from_f32<T>(v);
-            const float vr = to_f32<T>(o.e[e]);   // the value the consumer will read
-            ps += vr;
-            pq += vr * vr;
+        mfma2(acc[i][j], w8[i], xc[j]);
+      }
+      if constexpr (2 + m < NB) rd_block(std::integral_constant<int, 2 + m>{});
+      // staging: weight pieces behind MFMAs 4, 6, (8); one halo piece behind MFMA 10
+      if constexpr (m == MI) stage_w(std::integral_constant<int, 0>{}, ws2, st2, live_w);
+      if constexpr (m == MI + 2) stage_w(std::integral_constant<int, 1>{}, ws2, st2, live_w);
+      if constexpr (m == MI + 4) { if (g == 0) stage_w(std::integral_constant<int, 2>{}, ws2, st2, live_w); }
+      if constexpr (m == MI + 6) {
+        if (tap < nhq) {
+          switch (tap) {
+            case 0: stage_h(std::integral_constant<int, 0>{}, hb ^ 1, chunk + 1, live_h); break;
+            case 1: stage_h(std::integral_constant<int, 1>{}, hb ^ 1, chunk + 1, live_h); break;
+            case 2: stage_h(std::integral_constant<int, 2>{}, hb ^ 1, chunk + 1, live_h); break;
+            case 3: stage_h(std::integral_constant<int, 3>{}, hb ^ 1, chunk + 1, live_h); break;
+            case 4: stage_h(std::integral_constant<int, 4>{}, hb ^ 1, chunk + 1, live_h); break;
+            case 5: stage_h(std::integral_constant<int, 5>{}, hb ^ 1, chunk + 1, live_h); break;
+            default: stage_h(std::integral_constant<int, 6>{}, hb ^ 1, chunk + 1, live_h); break;
           }
-          if (mok) o.store(out + (long)m * p.ldo + cbase + i * 16);
         }
-        ps += __shfl_xor(ps, 16, 64); pq += __shfl_xor(pq, 16, 64);
-        ps += __shfl_xor(ps, 32, 64); pq += __shfl_xor(pq, 32, 64);
-        if (mok && (lane >> 4) == 0)
-          *reinterpret_cast<float2*>(p.ln_stats_out + ((long)(tn * 2 + g) * p.M + m) * 2) = float2{ps, pq};
-        continue;
       }
-      if (m >= p.M) continue;
-      if (slab) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-          if (i < nblk) *reinterpret_cast<f32x4*>(slab + (long)m * p.N + cbase + i * 16) = acc[i][j];
-        continue;
-      }
-      Quad<T> rq[NI], bq[NI];
-      if (rowb) {
-        const T* rp = rowb + (long)(p.howo_shift >= 0 ? m >> p.howo_shift : m / HoWo) * p.ldrb + cbase;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) if (i < nblk) bq[i].load(rp + i * 16);
-      }
-      if (res) {
-        const T* rp = res + (long)m * p.ldr + cbase;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) if (i < nblk) rq[i].load(rp + i * 16);
-      }
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        if (i >= nblk) continue;
-        Quad<T> o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = acc[i][j][e];
-          if (rowb) v += to_f32<T>(bq[i].e[e]);
-          if (res) v += to_f32<T>(rq[i].e[e]);
-          o.e[e] = from_f32<T>(v);
-        }
-        o.store(out + (long)m * p.ldo + cbase + i * 16);
-      }
-    }
-    return;
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    pp_wait_lgkm0();
+  };
+
+  // ---- prologue: halo of the first chunk, weights of steps 0 and 1 ----
+  pp_static_for<0, NHQ>([&](auto qc) {
+    if (decltype(qc)::value < nhq) stage_h(qc, 0, chunk0, 1);
+  });
+  {
+    Step s0{0, chunk0}, s1{1, chunk0};
+    stage_w(std::integral_constant<int, 0>{}, 0, s0, 1);
+    stage_w(std::integral_constant<int, 1>{}, 0, s0, 1);
+    if (g == 0) stage_w(std::integral_constant<int, 2>{}, 0, s0, 1);
+    stage_w(std::integral_constant<int, 0>{}, 1, s1, 1);
+    stage_w(std::integral_constant<int, 1>{}, 1, s1, 1);
+    if (g == 0) stage_w(std::integral_constant<int, 2>{}, 1, s1, 1);
   }
-  constexpr int ITEMS = BN / 32;                    // 8-column vectors per thread and pass (GEGLU: half of them)
-  const int nitems = geglu ? ITEMS / 2 : ITEMS;
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass) __syncthreads();
-    if ((wq >> 1) == pass) {
-      const int rbase = (wq & 1) * 64 + (lane & 15);
-      const int nblk = geglu ? NI / 2 : NI;
-#pragma unroll
-      for (int j = 0; j < MI; ++j)
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-          if (i < nblk)
-            *reinterpret_cast<f32x4*>(et + (rbase + j * 16) * C::EPI_LD + g * HNo + i * 16 + cl) = acc[i][j];
-    }
-    __syncthreads();
-    // ---- gather phase: everything this thread needs for its ITEMS vectors ----
-    float v[ITEMS][8];
-    int im[ITEMS], in_[ITEMS];
-    Quad<T> rq[ITEMS][2], bq[ITEMS][2];
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int idx = tid + it * 512;
-      const int row = geglu ? idx / (BN / 16) : idx / (BN / 8);   // constant divisors: no runtime integer division
-      const int c8 = (idx - row * tpr) * 8;
-      const int m = m0 + pass * 128 + row, n = ncol0 + c8;
-      const bool ok = it < nitems && m < p.M && n < Nvalid;
-      im[it] = ok ? m : -1;
-      in_[it] = n;
-      if (!ok) continue;
-      const float4 a = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8);
-      const float4 b4 = *reinterpret_cast<const float4*>(et + row * C::EPI_LD + c8 + 4);
-      v[it][0] = a.x; v[it][1] = a.y; v[it][2] = a.z; v[it][3] = a.w;
-      v[it][4] = b4.x; v[it][5] = b4.y; v[it][6] = b4.z; v[it][7] = b4.w;
-      if (slab) continue;
-      if (rowb) {
-        const T* rp = rowb + (long)(p.howo_shift >= 0 ? m >> p.howo_shift : m / HoWo) * p.ldrb + n;
-        bq[it][0].load(rp);
-        bq[it][1].load(rp + 4);
-      }
-      if (res) {
-        const T* rp = res + (long)m * p.ldr + n;
-        rq[it][0].load(rp);
-        rq[it][1].load(rp + 4);
-      }
-    }
-    // ---- combine + store ----
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int m = im[it], n = in_[it];
-      if (m < 0) continue;
-      if (slab) {
-        *reinterpret_cast<float4*>(slab + (long)m * p.N + n) = float4{v[it][0], v[it][1], v[it][2], v[it][3]};
-        *reinterpret_cast<float4*>(slab + (long)m * p.N + n + 4) = float4{v[it][4], v[it][5], v[it][6], v[it][7]};
-        continue;
-      }
-#pragma unroll
-      for (int hq = 0; hq < 2; ++hq) {
-        float* vv = v[it] + 4 * hq;
-        if (rowb) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) vv[e] += to_f32<T>(bq[it][hq].e[e]);
-        }
-        if (res) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) vv[e] += to_f32<T>(rq[it][hq].e[e]);
-        }
-        Quad<T> o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o.e[e] = from_f32<T>(vv[e]);
-        o.store(out + (long)m * p.ldo + n + 4 * hq);
-      }
-    }
+  // vmcnt at the head of a step: everything but what the PREVIOUS step issued (its nwq weight pieces + its halo piece)
+  auto wait_head = [&](int prev_halo) {
+    const int n = nwq + prev_halo;
+    if (n == 2) pp_wait_vm<2>(); else if (n == 3) pp_wait_vm<3>(); else pp_wait_vm<4>();
+  };
+  int tap = 0, hb = 0, ws = 0, ws1 = 1, ws2 = 2, s_glob = kt_begin;
+  int prev_halo = 0;                            // the prologue's last issue is a weight set: keep nwq in flight
+  auto one = [&](pp_u32x4 (&xc)[MI][2], pp_u32x4 (&xp)[MI][2]) {
+    wait_head(prev_halo);
+    __builtin_amdgcn_s_barrier();
+    step(s_glob, tap, hb, ws, ws2, xc, xp);
+    prev_halo = tap < nhq ? 1 : 0;
+    ++s_glob;
+    if (++tap == 9) { tap = 0; hb ^= 1; }
+    const int t3 = ws; ws = ws1; ws1 = ws2; ws2 = t3;
+  };
+  int t = 0;
+  for (; t + 1 < KT; t += 2) {
+    one(xa8, xb8);
+    one(xb8, xa8);
   }
+  if (KT & 1) one(xa8, xb8);
+  pp_wait_vm<0>();
+  if (KT & 1) {
+#pragma unroll
+    for (int j = 0; j < MI; ++j) mfma2(acc[NI - 1][j], w8[NI - 1], xa8[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < MI; ++j) mfma2(acc[NI - 1][j], w8[NI - 1], xb8[j]);
+  }
+  __builtin_amdgcn_s_barrier();
+
+  const int cl = 4 * (lane >> 4);
+  float4 bias_r[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    bias_r[i] = float4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && p.splitk <= 1) bias_r[i] = *reinterpret_cast<const float4*>(p.bias + n0 + g * C::HN + i * 16 + cl);
+  }
+  float4 ln_cs[1];
+  float ln_mu[1], ln_rs[1];
+  pp_epilogue<160, 0>(p, acc, bias_r, ln_cs, ln_mu, ln_rs, smem, tid, lane, g, wq, m0, n0, tn, zk);
 }
 
 // ---------------------------------------------------------------------------
@@ -1601,8 +1884,9 @@ int af_launch_cast_fp8(const void* x, void* y, long n, float mul, hipStream_t st
 AfGemmPlan g_af_last_plan = {0, 1, 0, 0, 1};
 // launches since af_gemm_plan_counts_reset: [0..5] by tile (implicit-GEMM / ping-pong kernels), [6] LDS-halo kernel,
 // [7] launches that sliced K (counted in their tile's slot as well), [8] / [9] ping-pong launches with the LayerNorm
-// consumer / statistics-producer epilogue, [10] ping-pong launches with fp8 operands
-long g_af_plan_counts[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+// consumer / statistics-producer epilogue, [10] ping-pong launches with fp8 operands, [11] eight-wave halo launches
+// (counted under tile 5 as well)
+long g_af_plan_counts[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 
 // tile: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64
@@ -1722,11 +2006,20 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
       }
     }
   }
+  // eight-wave LDS-halo kernel for the 3x3 / stride-1 convolutions the 256 x 160 ping-pong tile was chosen for: whole
+  // image rows per tile (Wo 16 / 32 / 64), K slices of whole channel chunks
+  if (pl.tile == 5 && pl.halo_tw == 0 && p.ks == 3 && p.stride == 1 && p.pad == 1 && p.up == 0 && p.Ho == p.Hi && p.Wo == p.Wi &&
+      (p.Wo == 16 || p.Wo == 32 || p.Wo == 64) && (p.Ho & (p.Ho - 1)) == 0 && p.Ho >= 256 / p.Wo && p.M % 256 == 0 &&
+      p.K == 9 * p.Cin && p.ldc >= p.Cin && g_af_knobs.conv_halo8 && !p.ln_stats && !p.ln_stats_out) {
+    pl.halo_tw = 256;
+    while (pl.splitk > 1 && (p.Cin / 64) % pl.splitk != 0) --pl.splitk;   // a K slice = whole channel chunks
+  }
   const int ft = g_af_knobs.gemm_tile;
   if (ft >= 0 && ft < 4 && !(geglu && bn[ft] != 128)) pl.tile = ft;
   const int fs = g_af_knobs.gemm_splitk;
   if (fs >= 1 && batch == 1 && !geglu) pl.splitk = fs > KT ? KT : fs;
-  if (pl.splitk > 1) pl.halo_tw = 0;
+  if (pl.splitk > 1 && pl.halo_tw != 256) pl.halo_tw = 0;
+  if (pl.halo_tw == 256 && (pl.tile != 5 || (p.Cin / 64) % pl.splitk != 0)) pl.halo_tw = 0;
   if (pl.splitk > 1) pl.ws_bytes = (size_t)pl.splitk * p.M * p.N * sizeof(float);
   plan_group_m(pl, p);
   return pl;
@@ -1737,8 +2030,9 @@ static void plan_group_m(AfGemmPlan& pl, const ConvGemmParams& p) {
   {
     // grouped tile order: minimise  X_bytes * (NT / gn) + W_bytes * (MT / gm)  with gm * gn = workgroups resident
     // per XCD (32 CUs x blocks per CU)
-    const int tbm = pl.halo_tw ? 128 : (pl.tile >= 4 ? 256 : bm[pl.tile]);
-    const int tbn = pl.halo_tw ? ((pl.tile == 0 || pl.tile == 1) ? 128 : 64) : (pl.tile == 5 ? 160 : pl.tile == 4 ? 128 : bn[pl.tile]);
+    const bool h4 = pl.halo_tw != 0 && pl.halo_tw != 256;   // the four-wave halo kernel (128-pixel patches)
+    const int tbm = h4 ? 128 : (pl.tile >= 4 ? 256 : bm[pl.tile]);
+    const int tbn = h4 ? ((pl.tile == 0 || pl.tile == 1) ? 128 : 64) : (pl.tile == 5 ? 160 : pl.tile == 4 ? 128 : bn[pl.tile]);
     const int MT = (p.M + tbm - 1) / tbm, NT = (p.N + tbn - 1) / tbn;
     const int resident = pl.tile >= 4 ? 32 : 32 * ((tbm * tbn >= 128 * 128) ? 2 : 3);
     // activation bytes a column of tiles streams per unit of M: every tap re-reads the input unless the taps of a channel
@@ -1793,6 +2087,9 @@ static int launch_pp_one(const ConvGemmParams& p, dim3 grid, hipStream_t stream)
 template <int BN, int LNMODE, bool GATHER> static int launch_pp_sched(const ConvGemmParams& p, dim3 grid, hipStream_t stream) {
   int sched = g_af_knobs.pp_sched;
   if (sched >= 2 && GATHER && !(p.up == 0 && p.ks * p.ks <= 31)) sched = 1;   // merged gathers exist with tap masks only
+  // GEGLU launches (K = 320 .. 1280, an epilogue of ~1/3 of the workgroup's time that wants its bias and LayerNorm operands
+  // fetched before the loop): the round-1 schedule measures 3-5 % ahead of both newer ones there
+  if (p.epilogue == AF_EPI_GEGLU && g_af_knobs.pp_sched == 2) sched = 0;
   switch (sched) {
     case 0: return launch_pp_one<BN, LNMODE, GATHER, false, 0>(p, grid, stream);
     case 1: return launch_pp_one<BN, LNMODE, GATHER, false, 1>(p, grid, stream);
@@ -1875,6 +2172,15 @@ static int launch_conv_gemm_fp8(ConvGemmParams p, hipStream_t stream, const AfGe
   return 0;
 }
 
+static int launch_halo8(const ConvGemmParams& p, hipStream_t stream) {
+  static unsigned long long attr_done = 0;
+  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&conv3x3_halo8_kernel), Halo8Cfg::LDS_BYTES)) return rc;
+  dim3 grid((p.M / 256) * (p.N / 160), 1, p.splitk > 1 ? p.splitk : 1);
+  hipLaunchKernelGGL(conv3x3_halo8_kernel, grid, dim3(512), Halo8Cfg::LDS_BYTES, stream, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
 template <typename T, int TW, int BN> static int launch_halo(const ConvGemmParams& p, hipStream_t stream) {
   using C = HaloCfg<TW, BN>;
   static unsigned long long attr_done = 0;
@@ -1924,7 +2230,8 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   p.splitk = pl.splitk;
   p.ws = ws;
   g_af_last_plan = pl;
-  g_af_plan_counts[pl.halo_tw ? 6 : (pl.tile >= 0 && pl.tile < 6 ? pl.tile : 0)] += 1;
+  g_af_plan_counts[(pl.halo_tw && pl.halo_tw != 256) ? 6 : (pl.tile >= 0 && pl.tile < 6 ? pl.tile : 0)] += 1;
+  if (pl.halo_tw == 256) g_af_plan_counts[11] += 1;
   if (pl.splitk > 1) g_af_plan_counts[7] += 1;
   if (p.ln_stats) g_af_plan_counts[8] += 1;
   if (p.ln_stats_out) g_af_plan_counts[9] += 1;
@@ -1945,6 +2252,23 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   if ((p.ln_stats || p.ln_stats_out) && !(pl.tile >= 4 && !pl.halo_tw)) {
     af_set_error_msg("conv_gemm: LayerNorm-fused launch planned on a kernel without that epilogue (tile %d)", pl.tile);
     return -1;
+  }
+  if (pl.halo_tw == 256) {
+    if constexpr (sizeof(T) == 2) {
+      rc = launch_halo8(p, stream);
+    } else {
+      af_set_error_msg("conv_gemm: the eight-wave halo kernel is bf16 only");
+      return -1;
+    }
+    if (rc) return rc;
+    if (p.splitk > 1) {
+      const long nq = (long)p.M * (p.N >> 2);
+      unsigned blocks = (unsigned)((nq + 255) / 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, stream, p);
+      HIP_CHECK_RET(hipGetLastError());
+    }
+    return 0;
   }
   if (pl.halo_tw) {
     const bool bn128 = pl.tile == 0 || pl.tile == 1;

@@ -25,6 +25,8 @@ ap.add_argument("--lib", default="", help="lab only: another build of libadaface
 args = ap.parse_args()
 if args.lib:
     _lib._LIB_PATH = Path(args.lib).resolve()
+    _probe = C.CDLL(str(_lib._LIB_PATH))
+    _lib._SIGS[:] = [s_ for s_ in _lib._SIGS if hasattr(_probe, s_[0])]   # older builds lack newer entry points
 lib = _lib.load()
 for kv in args.knob:
     k, v = kv.split("=")

@@ -154,6 +154,7 @@ def test_conv2d_pingpong(gpu, report, knobs, B, Cin, H, W, Cout, ks, stride, up,
     """The eight-wave 256x{160,128} ping-pong kernel (conv_gemm_pp_kernel), forced regardless of grid fill."""
     from adaface_amd import ops
     knobs("gemm_pp_minfill", 0)
+    knobs("conv_halo8", 0)      # the gathering kernel (the LDS-halo variant has its own test below)
     if splitk > 1:
         knobs("gemm_splitk", splitk)
     dtype = "bf16"
@@ -171,6 +172,43 @@ def test_conv2d_pingpong(gpu, report, knobs, B, Cin, H, W, Cout, ks, stride, up,
     tile, sk, halo = _last_plan()
     assert tile in (4, 5) and halo == 0 and (splitk == 1 or sk == splitk), (tile, sk, halo)  # planner may slice K itself
     _cmp(report, f"pp conv{ks}x{ks} {Cin}->{Cout}@{H}x{W} s{stride} up{int(up)} sk{splitk}", got, ref, dtype)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,bias,res,splitk", [
+    (2, 320, 64, 64, 320, True, True, 1),      # the dominant ResBlock conv: 4-row tiles of a 64-wide image, 5 chunks (odd K)
+    (1, 64, 64, 64, 160, True, False, 1),      # one chunk: the prologue's halo only
+    (2, 128, 32, 32, 320, False, True, 1),     # 8-row tiles, 2 chunks (even number of steps)
+    (4, 640, 16, 16, 160, True, False, 1),     # one image per tile
+    (1, 960, 32, 32, 320, True, True, 1),      # 15 chunks
+    (2, 1280, 16, 16, 1280, True, True, 2),    # K sliced into two runs of 10 chunks + reduce
+    (3, 192, 64, 64, 160, True, False, 3),     # three slices of one chunk each
+])
+def test_conv2d_halo8(gpu, report, knobs, B, Cin, H, W, Cout, bias, res, splitk):
+    """The eight-wave LDS-halo 3x3 kernel (conv3x3_halo8_kernel) against torch AND against the gathering kernel on the same
+    inputs: both walk K as (channel chunk, tap) with the same tiles, so their bf16 results agree bit for bit."""
+    from adaface_amd import _lib, ops
+    knobs("gemm_pp_minfill", 0)
+    knobs("gemm_splitk", splitk)          # the same K slices for both kernels (the planner would slice some of these)
+    g = torch.Generator().manual_seed(Cin + Cout + H + 11)
+    x = _q(torch.randn(B, Cin, H, W, generator=g), "bf16")
+    w = _q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9), "bf16")
+    b = torch.randn(Cout, generator=g) * 0.1 if bias else None
+    ref = F.conv2d(x, w, b, padding=1)
+    r = _q(torch.randn(ref.shape, generator=g), "bf16") if res else None
+    if res:
+        ref = ref + r
+    args = (x.to(gpu), w.to(gpu), None if b is None else b.to(gpu))
+    kw = dict(residual=None if r is None else r.to(gpu), dtype="bf16")
+    _lib.plan_counts(reset=True)
+    got = ops.conv2d(*args, **kw)
+    pc = _lib.plan_counts(reset=True)
+    tile, sk, halo = _last_plan()
+    assert pc["halo8"] == 1 and tile == 5 and halo == 256 and sk == splitk, (pc, tile, sk, halo)
+    _cmp(report, f"halo8 conv3x3 {Cin}->{Cout}@{H}x{W} B{B} sk{splitk}", got, ref, "bf16")
+    knobs("conv_halo8", 0)
+    gathered = ops.conv2d(*args, **kw)
+    assert _lib.plan_counts(reset=True)["halo8"] == 0
+    assert torch.equal(got, gathered), (got - gathered).abs().max().item()
 
 
 @pytest.mark.parametrize("M,K,N,bias,res,geglu", [
