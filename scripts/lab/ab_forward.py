@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default="")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--fp8", action="store_true")
+ap.add_argument("--knob", action="append", default=[])
 args = ap.parse_args()
 if args.lib:
     _lib._LIB_PATH = Path(args.lib).resolve()
@@ -27,6 +28,9 @@ from adaface_amd.engine import Engine  # noqa: E402
 from adaface_amd.synth import synth_weights_into  # noqa: E402
 from oracle import ldm_oracle as O  # noqa: E402  (parameter shapes only)
 
+for kv in args.knob:
+    k_, v_ = kv.split("=")
+    _lib.set_knob(k_, int(v_))
 dev = torch.device("cuda:0")
 cfg = O.SD15_UNET
 kw = dict(in_channels=cfg.in_channels, model_channels=cfg.model_channels, out_channels=cfg.out_channels,
@@ -53,4 +57,17 @@ for rnd in range(3):
         eng.unet_forward(x, t, out)
     torch.cuda.synchronize()
     best = min(best, (time.perf_counter() - t0) / args.reps)
-print(f"{args.lib or 'HEAD'}{' fp8' if args.fp8 else ''}: UNet forward Bf=16: {best * 1e3:.3f} ms  (-> {8 / (50 * best + 0.026):.2f} images/s at 50 steps + 26 ms VAE)")
+# per-class kernel time of one forward (HIP-event brackets around every launch: slows the forward, classes comparable)
+lib = _lib.load()
+lib.af_prof_reset(); lib.af_prof_set_stride(1) if hasattr(lib, "af_prof_set_stride") else None
+lib.af_prof_enable(0x1ff)
+eng.unet_forward(x, t, out)
+torch.cuda.synchronize()
+lib.af_prof_enable(0)
+n = 9
+ms = (C.c_double * n)(); la = (C.c_int64 * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)()
+lib.af_prof_collect(n, ms, la, fl, by)
+names = ["gemm_other", "attention", "groupnorm", "layernorm", "other", "pp160_gather", "pp160_plain", "pp128", "fp8"]
+print("   per-class ms per forward: " + ", ".join(f"{names[i]} {ms[i]:.2f} ({la[i]})" for i in range(n) if la[i])
+      + f" | gemm total {ms[0] + ms[5] + ms[6] + ms[7] + ms[8]:.2f}")
+print(f"{args.lib or 'HEAD'}{' fp8' if args.fp8 else ''} {' '.join(args.knob)}: UNet forward Bf=16: {best * 1e3:.3f} ms  (-> {8 / (50 * best + 0.026):.2f} images/s at 50 steps + 26 ms VAE)")
