@@ -42,7 +42,7 @@ static inline int af_ensure_dynamic_lds(unsigned long long& done_mask, const voi
 // classes 5-7 split the eight-wave ping-pong kernel out of the conv/linear class by instantiation, so that the bench can
 // quote ONE kernel (conv_gemm_pp_kernel<160, true>, the 3x3 convolutions) with its own launch count and duration
 enum { AF_K_CONV_GEMM = 0, AF_K_ATTENTION = 1, AF_K_GROUPNORM = 2, AF_K_LAYERNORM = 3, AF_K_OTHER = 4,
-       AF_K_PP160_GATHER = 5, AF_K_PP160_PLAIN = 6, AF_K_PP128 = 7, AF_K_PP_FP8 = 8, AF_K_COUNT = 9 };
+       AF_K_PP160_GATHER = 5, AF_K_PP160_PLAIN = 6, AF_K_PP128 = 7, AF_K_PP_FP8 = 8, AF_K_HALO8 = 9, AF_K_COUNT = 10 };
 extern int g_af_prof_enabled;
 extern int g_af_prof_stride;              // bracket only every stride-th launch of a class (>= 1)
 extern long g_af_prof_seen[AF_K_COUNT];   // launches seen per class since af_prof_reset

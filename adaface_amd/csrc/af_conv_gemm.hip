@@ -2244,8 +2244,9 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   p.pp_epilogue = g_af_knobs.pp_direct < 0 ? 0 : (g_af_knobs.pp_direct ? 2 : 1);
   p.k_tap_inner = (p.ks > 1 && g_af_knobs.conv_tap_inner) ? 1 : 0;
   p.fast_taps = g_af_knobs.conv_fast_taps;
-  const int prof_cls = pl.tile == 5 ? ((p.ks == 1 && p.pad == 0) ? AF_K_PP160_PLAIN : AF_K_PP160_GATHER)
-                                     : (pl.tile == 4 ? AF_K_PP128 : AF_K_CONV_GEMM);
+  const int prof_cls = pl.halo_tw == 256 ? AF_K_HALO8
+                       : pl.tile == 5 ? ((p.ks == 1 && p.pad == 0) ? AF_K_PP160_PLAIN : AF_K_PP160_GATHER)
+                                      : (pl.tile == 4 ? AF_K_PP128 : AF_K_CONV_GEMM);
   AfProfScope prof(prof_cls, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K) * batch,
                    ((double)p.M * p.K / (p.ks * p.ks) + (double)p.N * p.K + (double)p.M * p.N) * batch * sizeof(T));
   int rc;

@@ -74,7 +74,7 @@ static int* knob_slot(const char* name) {
 // ----------------------------------------------------------------------------
 int g_af_prof_enabled = 0;
 int g_af_prof_stride = 1;
-long g_af_prof_seen[AF_K_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+long g_af_prof_seen[AF_K_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 namespace {
 struct ProfRec {
   hipEvent_t start, stop;

@@ -45,10 +45,10 @@ PEAK_F32 = 157.3e12
 PEAK_MXFP8 = 5.0e15     # dense block-scaled fp8 MFMA peak (the fp8 convolutions' own roofline)
 # af_prof classes (include/adaface_hip.h)
 K_NAMES = ["conv_gemm_other", "attention", "groupnorm", "layernorm", "other", "conv_gemm_pp<160,gather>",
-           "conv_gemm_pp<160,plain>", "conv_gemm_pp<128>", "conv_gemm_pp<fp8>"]
-GEMM_CLASSES = (0, 5, 6, 7, 8)
-DOMINANT = 5            # conv_gemm_pp_kernel<160, true, ...>: the 3x3 convolutions, the largest single kernel of a step
-DOMINANT_KERNEL = "conv_gemm_pp_kernel<160, true, 0, false, 2>"
+           "conv_gemm_pp<160,plain>", "conv_gemm_pp<128>", "conv_gemm_pp<fp8>", "conv3x3_halo8"]
+GEMM_CLASSES = (0, 5, 6, 7, 8, 9)
+DOMINANT = 9            # conv3x3_halo8_kernel: the 3x3 / stride-1 convolutions, the largest single kernel of a bf16 step
+DOMINANT_KERNEL = "conv3x3_halo8_kernel"
 DOMINANT_FP8 = 8        # fp8 mode: the same convolutions with e4m3 operands (both tile widths in one class)
 DOMINANT_FP8_KERNEL = "conv_gemm_pp_kernel<160|128, true, 0, true, 2>"
 
@@ -266,8 +266,9 @@ def main():
         if launches[d]:
             traffic, tsrc = traffic_record() if d == DOMINANT else (None, None)
             ach = flops[d] / (ms[d] * 1e-3)
-            kname = {DOMINANT: DOMINANT_KERNEL + " (3x3 / strided convolutions of the UNet and VAE: eight-wave 256x160x64 "
-                               "implicit GEMM, LDS-DMA ring, merged staging/compute schedule)",
+            kname = {DOMINANT: DOMINANT_KERNEL + " (3x3 / stride-1 convolutions of the UNet at 64x64 / 32x32 / 16x16: eight-wave "
+                               "256x160x64 implicit GEMM, input halo resident in LDS, weight tiles by LDS-DMA, merged "
+                               "staging/compute schedule)",
                      DOMINANT_FP8: DOMINANT_FP8_KERNEL + " (ResBlock 3x3 convolutions with OCP e4m3 operands on "
                                    "v_mfma_scale_f32_16x16x128_f8f6f4; peak = dense block-scaled fp8)"}.get(
                 d, "conv_gemm_kernel / conv3x3_halo_kernel (f32 parity mode)")

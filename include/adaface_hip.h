@@ -153,7 +153,8 @@ int64_t af_arena_bytes(af_handle* h);
  * classes: 0 conv_gemm (implicit-GEMM conv/linear on the four-wave / halo kernels), 1 attention, 2 groupnorm,
  * 3 layernorm, 4 other, 5 conv_gemm_pp_kernel<160,gather> (3x3 / strided convs on the eight-wave ping-pong kernel),
  * 6 conv_gemm_pp_kernel<160,plain> (1x1 convs / linears), 7 conv_gemm_pp_kernel<128,*> (GEGLU, VAE widths),
- * 8 conv_gemm_pp_kernel<*,*,0,true> (fp8 operands, af_set_fp8).
+ * 8 conv_gemm_pp_kernel<*,*,0,true> (fp8 operands, af_set_fp8), 9 conv3x3_halo8_kernel (3x3 / stride-1 convolutions with an
+ * LDS-resident input halo: the largest single kernel of a bf16 step).
  * While enabled every launch of a class is bracketed by hipEventRecord on ITS stream; af_prof_collect
  * sums elapsed ms, launch counts and the ALGORITHMIC flops / bytes of those launches per class. */
 int af_prof_enable(int class_mask); /* bit c set = time class c; 0 = off */

@@ -35,7 +35,7 @@ dev = torch.device("cuda:0")
 Bf = args.bf
 
 
-GEMM_CLASSES = (0, 5, 6, 7)   # four-wave / halo kernels + the three ping-pong instantiations (include/adaface_hip.h)
+GEMM_CLASSES = (0, 5, 6, 7, 9)   # four-wave / halo kernels + the three ping-pong instantiations (include/adaface_hip.h)
 
 
 def timed(cls, fn):
@@ -48,7 +48,7 @@ def timed(cls, fn):
         fn()
     torch.cuda.synchronize()
     lib.af_prof_enable(0)
-    n = 9
+    n = 10
     ms = (C.c_double * n)(); la = (C.c_int64 * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)()
     lib.af_prof_collect(n, ms, la, fl, by)
     tms, tla = sum(ms[c] for c in classes), sum(la[c] for c in classes)

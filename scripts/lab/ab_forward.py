@@ -60,14 +60,14 @@ for rnd in range(3):
 # per-class kernel time of one forward (HIP-event brackets around every launch: slows the forward, classes comparable)
 lib = _lib.load()
 lib.af_prof_reset(); lib.af_prof_set_stride(1) if hasattr(lib, "af_prof_set_stride") else None
-lib.af_prof_enable(0x1ff)
+lib.af_prof_enable(0x3ff)
 eng.unet_forward(x, t, out)
 torch.cuda.synchronize()
 lib.af_prof_enable(0)
-n = 9
+n = 10
 ms = (C.c_double * n)(); la = (C.c_int64 * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)()
 lib.af_prof_collect(n, ms, la, fl, by)
-names = ["gemm_other", "attention", "groupnorm", "layernorm", "other", "pp160_gather", "pp160_plain", "pp128", "fp8"]
+names = ["gemm_other", "attention", "groupnorm", "layernorm", "other", "pp160_gather", "pp160_plain", "pp128", "fp8", "halo8"]
 print("   per-class ms per forward: " + ", ".join(f"{names[i]} {ms[i]:.2f} ({la[i]})" for i in range(n) if la[i])
-      + f" | gemm total {ms[0] + ms[5] + ms[6] + ms[7] + ms[8]:.2f}")
+      + f" | gemm total {ms[0] + ms[5] + ms[6] + ms[7] + ms[8] + ms[9]:.2f}")
 print(f"{args.lib or 'HEAD'}{' fp8' if args.fp8 else ''} {' '.join(args.knob)}: UNet forward Bf=16: {best * 1e3:.3f} ms  (-> {8 / (50 * best + 0.026):.2f} images/s at 50 steps + 26 ms VAE)")

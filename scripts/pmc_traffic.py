@@ -24,7 +24,7 @@ def load(d, counter):
 
 
 def klass(name):
-    if "conv_gemm_kernel" in name or "conv_gemm_pp_kernel" in name or "conv3x3_halo_kernel" in name or "splitk_reduce" in name:
+    if "conv_gemm_kernel" in name or "conv_gemm_pp_kernel" in name or "conv3x3_halo" in name or "splitk_reduce" in name:
         return "conv_gemm"
     if "attn_kernel" in name:
         return "attention"
