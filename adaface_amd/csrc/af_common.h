@@ -84,6 +84,7 @@ struct AfKnobs {
   int ln_fuse;              // AF_LN_FUSE              0 = stand-alone LayerNorm kernels in front of the transformer GEMMs
   int conv_halo8;           // AF_CONV_HALO8           0 = 3x3 / stride-1 convs stay on the gathering eight-wave kernel (no LDS halo)
   int conv_fast_taps;       // AF_CONV_FAST_TAPS       0 = ping-pong convs recompute every tap's bounds check in the staging phase
+  int pp_stagger;           // AF_PP_STAGGER           merged schedule: 1 = the two wave groups issue their LDS-DMA pieces behind alternate MFMAs
   int pp_sched;             // AF_PP_SCHED             eight-wave kernel: 0 = round-1 compute phase (two K halves, a full LDS drain
                             //                         after each), 1 = block-ordered compute phase, 2 = merged (no staging phase)
 };
@@ -248,6 +249,7 @@ struct ConvGemmParams {
   // UNITS, unit u = (channel chunk u / taps, tap u % taps), zero-padded to a multiple of 128 = K; Cin = real channel
   // count (multiple of 64).  Scales are powers of two applied by the MFMA itself (E8M0): w_scale[n] per output channel,
   // x_scale_e8 for the whole activation tensor (the producer multiplied by 2^(127 - x_scale_e8)).
+  int pp_stagger;         // merged schedule (set by the launcher): the wave groups stage behind alternate MFMAs
   int fast_taps;          // ping-pong kernel (set by the launcher): per-piece tap validity masks instead of per-tap bounds arithmetic
   int fp8;
   const unsigned char* w_scale;

@@ -1137,11 +1137,15 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
           if (!(lab & 4)) mfma8(acc[i][j], w8[i], xc[j], wsc8[FP8 ? i : 0]);
         }
         if constexpr (2 + m < NB) rd_block(std::integral_constant<int, 2 + m>{});
-        if constexpr (MG && m >= MI && (m - MI) % 2 == 0 && (m - MI) / 2 < NPMAX)
-          if (!(lab & 1)) stage_piece(std::integral_constant<int, (m - MI) / 2>{}, ftc, sbase, sc);
+        if constexpr (MG && m >= MI && (m - MI) / 2 < NPMAX) {
+          // (the two waves of a SIMD issue their pieces behind alternate MFMAs: group 0 behind the even ones, group 1 odd)
+          if (!(lab & 1) && (g == ((m - MI) & 1) || !p.pp_stagger)) {
+            if (p.pp_stagger || ((m - MI) & 1) == 0) stage_piece(std::integral_constant<int, (m - MI) / 2>{}, ftc, sbase, sc);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       });
-      static_assert(!MG || MI + 2 * (NPMAX - 1) < MI * NI, "merged schedule: a staging slot behind an MFMA for every piece");
+      static_assert(!MG || MI + 2 * (NPMAX - 1) + 1 < MI * NI, "merged schedule: a staging slot behind an MFMA for every piece");
       pp_wait_lgkm0();       // every read of the tile is back (the last weight block included)
     }
   };
@@ -1379,6 +1383,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo8_kernel(const ConvGemmParams
   };
   const int nchunks_all = p.Cin >> 6;
   const int step_end = kt_begin + KT;          // first step (global index) that does not exist
+  const bool stg = p.pp_stagger != 0;
 
   // one K step: compute (chunk, tap) from halo buffer hb and weight slot ws while staging the weights of step + 2 into
   // slot ws2 and, during the first nhq taps, one halo piece of chunk + 1 into the other halo buffer
@@ -1435,12 +1440,15 @@ __global__ __launch_bounds__(512) void conv3x3_halo8_kernel(const ConvGemmParams
         mfma2(acc[i][j], w8[i], xc[j]);
       }
       if constexpr (2 + m < NB) rd_block(std::integral_constant<int, 2 + m>{});
-      // staging: weight pieces behind MFMAs 4, 6, (8); one halo piece behind MFMA 10
-      if constexpr (m == MI) stage_w(std::integral_constant<int, 0>{}, ws2, st2, live_w);
-      if constexpr (m == MI + 2) stage_w(std::integral_constant<int, 1>{}, ws2, st2, live_w);
+      // staging: weight pieces behind MFMAs 4, 6, (8) and one halo piece behind MFMA 10 for waves 0-3; their SIMD partners
+      // (waves 4-7) one MFMA later each, so that the two waves of a SIMD do not stall on their LDS-DMA issue together
+      if constexpr (m == MI) { if (g == 0 || !stg) stage_w(std::integral_constant<int, 0>{}, ws2, st2, live_w); }
+      if constexpr (m == MI + 1) { if (g == 1 && stg) stage_w(std::integral_constant<int, 0>{}, ws2, st2, live_w); }
+      if constexpr (m == MI + 2) { if (g == 0 || !stg) stage_w(std::integral_constant<int, 1>{}, ws2, st2, live_w); }
+      if constexpr (m == MI + 3) { if (g == 1 && stg) stage_w(std::integral_constant<int, 1>{}, ws2, st2, live_w); }
       if constexpr (m == MI + 4) { if (g == 0) stage_w(std::integral_constant<int, 2>{}, ws2, st2, live_w); }
-      if constexpr (m == MI + 6) {
-        if (tap < nhq) {
+      if constexpr (m == MI + 6 || m == MI + 7) {
+        if (tap < nhq && (stg ? g == (m - MI - 6) : m == MI + 6)) {
           switch (tap) {
             case 0: stage_h(std::integral_constant<int, 0>{}, hb ^ 1, chunk + 1, live_h); break;
             case 1: stage_h(std::integral_constant<int, 1>{}, hb ^ 1, chunk + 1, live_h); break;
@@ -2158,6 +2166,7 @@ static int launch_conv_gemm_fp8(ConvGemmParams p, hipStream_t stream, const AfGe
   p.pp_epilogue = g_af_knobs.pp_direct < 0 ? 0 : (g_af_knobs.pp_direct ? 2 : 1);
   p.k_tap_inner = 1;
   p.fast_taps = g_af_knobs.conv_fast_taps;
+  p.pp_stagger = g_af_knobs.pp_stagger;
   AfProfScope prof(AF_K_PP_FP8, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K),
                    (double)p.M * p.Cin + (double)p.N * p.K + (double)p.M * p.N * 2.0);
   const int rc = pl.tile == 4 ? launch_pp8<128>(p, stream) : launch_pp8<160>(p, stream);
@@ -2244,6 +2253,7 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   p.pp_epilogue = g_af_knobs.pp_direct < 0 ? 0 : (g_af_knobs.pp_direct ? 2 : 1);
   p.k_tap_inner = (p.ks > 1 && g_af_knobs.conv_tap_inner) ? 1 : 0;
   p.fast_taps = g_af_knobs.conv_fast_taps;
+  p.pp_stagger = g_af_knobs.pp_stagger;
   const int prof_cls = pl.halo_tw == 256 ? AF_K_HALO8
                        : pl.tile == 5 ? ((p.ks == 1 && p.pad == 0) ? AF_K_PP160_PLAIN : AF_K_PP160_GATHER)
                                       : (pl.tile == 4 ? AF_K_PP128 : AF_K_CONV_GEMM);

@@ -53,6 +53,7 @@ AfKnobs g_af_knobs = {
     knob_env("AF_PP_DIRECT", -1),      knob_env("AF_ATTN_W4", 1),         knob_env("AF_ATTN_RING", 1),
     knob_env("AF_GN_SMALL", 1),        knob_env("AF_GN_FOLD", 1),         knob_env("AF_CONV_TAP_INNER", 1),
     knob_env("AF_LN_FUSE", 1),         knob_env("AF_CONV_HALO8", 1), knob_env("AF_CONV_FAST_TAPS", 1),
+    knob_env("AF_PP_STAGGER", 1),
     knob_env("AF_PP_SCHED", 2)};
 static const AfKnobs g_af_knobs_initial = g_af_knobs;
 static int* knob_slot(const char* name) {
@@ -62,7 +63,7 @@ static int* knob_slot(const char* name) {
       {"gemm_tile", &AfKnobs::gemm_tile}, {"gemm_splitk", &AfKnobs::gemm_splitk}, {"gemm_groupm", &AfKnobs::gemm_groupm},
       {"gemm_dma", &AfKnobs::gemm_dma}, {"pp_direct", &AfKnobs::pp_direct}, {"attn_w4", &AfKnobs::attn_w4}, {"attn_ring", &AfKnobs::attn_ring},
       {"gn_small", &AfKnobs::gn_small}, {"gn_fold", &AfKnobs::gn_fold}, {"conv_tap_inner", &AfKnobs::conv_tap_inner}, {"ln_fuse", &AfKnobs::ln_fuse},
-      {"conv_halo8", &AfKnobs::conv_halo8}, {"conv_fast_taps", &AfKnobs::conv_fast_taps}, {"pp_sched", &AfKnobs::pp_sched}};
+      {"conv_halo8", &AfKnobs::conv_halo8}, {"conv_fast_taps", &AfKnobs::conv_fast_taps}, {"pp_stagger", &AfKnobs::pp_stagger}, {"pp_sched", &AfKnobs::pp_sched}};
   if (!name) return nullptr;
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) return &(g_af_knobs.*(t.m));
