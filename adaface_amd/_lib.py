@@ -96,6 +96,7 @@ _SIGS = [
     ("af_op_attention", C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
     ("af_clip_embed_tokens", C.c_int, [_P, _P, C.c_int64, _P, _P]),
     ("af_clip_text_forward", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P]),
+    ("af_clip_text_forward3", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P, _P]),
     ("af_op_timestep_embedding", C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGS]

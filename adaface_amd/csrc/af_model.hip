@@ -1461,14 +1461,16 @@ static int vae_encode_impl(af_handle* h, hipStream_t s, const float* x_dev, floa
 // text_model_forward after the embedding lookup (encoders/modules.py:299-371): + position embeddings, L pre-LN layers with
 // the causal mask (CLIPEncoderLayer: x += out_proj(attn(LN1 x)); x += fc2(quick_gelu(fc1(LN2 x)))), blend of the last two
 // hidden states, final LayerNorm.
+// (w_prev2: weight of encoder_states[-3], the input of the second-to-last layer: the zero-shot identity path blends three)
 static int clip_forward_impl(af_handle* h, hipStream_t s, const float* emb_dev, int Bn, int T, float w_prev, float w_last,
-                             float* out_dev) {
+                             float* out_dev, float w_prev2 = 0.f) {
   Runner R(h, s);
   const af_config& c = h->cfg;
   const int dt = h->dtype, D = c.clip_hidden, F = c.clip_intermediate, H = c.clip_heads, dh = D / H;
   R.A.off = 0;
   Act x = R.alloc_act(Bn, T, 1, D);
   Act xprev = R.alloc_act(Bn, T, 1, D);
+  Act xprev2 = R.alloc_act(Bn, T, 1, D);
   Act n = R.alloc_act(Bn, T, 1, D);
   Act qkv = R.alloc_act(Bn, T, 1, 3 * D);
   Act a = R.alloc_act(Bn, T, 1, D);
@@ -1484,6 +1486,8 @@ static int clip_forward_impl(af_handle* h, hipStream_t s, const float* emb_dev, 
     const ClipLayerW& w = h->clip_layers[i];
     if (i == L - 1 && !R.dry)   // encoder_states[-2] = the input of the last layer
       HIP_CHECK_RET(hipMemcpyAsync(xprev.p, x.p, (size_t)rows * D * esize(dt), hipMemcpyDeviceToDevice, s));
+    if (i == L - 2 && w_prev2 != 0.f && !R.dry)   // encoder_states[-3]
+      HIP_CHECK_RET(hipMemcpyAsync(xprev2.p, x.p, (size_t)rows * D * esize(dt), hipMemcpyDeviceToDevice, s));
     AF_TRY(R.layernorm(w.ln1, x, n));
     AF_TRY(R.conv(w.qkv, n, qkv, 1, 0, nullptr, nullptr, 0));
     AF_TRY(R.attention(qkv.p, 3 * D, (long)T * 3 * D, R.elem_ptr(qkv.p, D), 3 * D, (long)T * 3 * D, R.elem_ptr(qkv.p, 2 * D),
@@ -1499,6 +1503,9 @@ static int clip_forward_impl(af_handle* h, hipStream_t s, const float* emb_dev, 
     if (L >= 1)
       AF_TRY(DISPATCH(dt, af_launch_blend2<bf16>(xprev.p, w_prev, x.p, w_last, n.p, rows * D, s),
                       af_launch_blend2<float>(xprev.p, w_prev, x.p, w_last, n.p, rows * D, s)));
+    if (L >= 2 && w_prev2 != 0.f)
+      AF_TRY(DISPATCH(dt, af_launch_blend2<bf16>(xprev2.p, w_prev2, n.p, 1.f, n.p, rows * D, s),
+                      af_launch_blend2<float>(xprev2.p, w_prev2, n.p, 1.f, n.p, rows * D, s)));
   }
   AF_TRY(R.layernorm(h->clip_final_ln, L >= 1 ? n : x, a));
   if (!R.dry)
@@ -1839,6 +1846,23 @@ int af_clip_text_forward(af_handle* h, const float* inputs_embeds_dev, int Bn, i
   if (rc) return rc;
   if (h->arena.peak > h->arena.cap) { HIP_CHECK_RET(hipStreamSynchronize(s)); AF_TRY(ensure_arena(h, h->arena.peak)); }
   return clip_forward_impl(h, s, inputs_embeds_dev, Bn, T, w_prev, w_last, out_dev);
+}
+
+int af_clip_text_forward3(af_handle* h, const float* inputs_embeds_dev, int Bn, int T, float w_prev2, float w_prev, float w_last,
+                          float* out_dev, void* stream) {
+  if (!h || !inputs_embeds_dev || !out_dev || Bn <= 0 || T <= 0) { af_set_error_msg("af_clip_text_forward3: bad argument"); return AF_ERR_INVALID; }
+  if (!h->cfg.build_clip) { af_set_error_msg("af_clip_text_forward3: handle has no CLIP text tower"); return AF_ERR_STATE; }
+  if (T > h->cfg.clip_max_pos) { af_set_error_msg("af_clip_text_forward3: %d tokens but only %d positions", T, h->cfg.clip_max_pos); return AF_ERR_INVALID; }
+  if (w_prev2 != 0.f && h->cfg.clip_layers < 2) { af_set_error_msg("af_clip_text_forward3: three states need two layers"); return AF_ERR_INVALID; }
+  HIP_CHECK_RET(hipSetDevice(h->device));
+  AF_TRY(check_loaded(h, "cond_stage_model.transformer.text_model."));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  h->arena.dry = true; h->arena.peak = 0;
+  int rc = clip_forward_impl(h, s, inputs_embeds_dev, Bn, T, w_prev, w_last, out_dev, w_prev2);
+  h->arena.dry = false;
+  if (rc) return rc;
+  if (h->arena.peak > h->arena.cap) { HIP_CHECK_RET(hipStreamSynchronize(s)); AF_TRY(ensure_arena(h, h->arena.peak)); }
+  return clip_forward_impl(h, s, inputs_embeds_dev, Bn, T, w_prev, w_last, out_dev, w_prev2);
 }
 
 int af_ddim_step(const float* x_dev, const float* eps_cond_dev, const float* eps_uncond_dev, const float* noise_dev,

@@ -227,6 +227,17 @@ class Engine:
               "af_clip_text_forward")
         return out
 
+    def clip_text_forward3(self, inputs_embeds: torch.Tensor, w_prev2: float, w_prev: float, w_last: float) -> torch.Tensor:
+        """As clip_text_forward with three blended hidden states (weights are used as given: normalise them first)."""
+        x = inputs_embeds.contiguous().float()
+        Bn, T, D = x.shape
+        if D != self.clip_cfg["hidden"]:
+            raise ValueError(f"inputs_embeds width {D} != hidden {self.clip_cfg['hidden']}")
+        out = torch.empty_like(x)
+        check(self._lib.af_clip_text_forward3(self._h, ptr(x), Bn, T, float(w_prev2), float(w_prev), float(w_last), ptr(out),
+                                              stream_ptr()), "af_clip_text_forward3")
+        return out
+
     def set_fp8(self, on: bool = True):
         """af_set_fp8: the UNet's ResBlock 3x3 convolutions read e4m3 activations / weights (bf16 engines only)."""
         check(self._lib.af_set_fp8(self._h, 1 if on else 0), "af_set_fp8")

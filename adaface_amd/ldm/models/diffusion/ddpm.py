@@ -154,9 +154,14 @@ class LatentDiffusion(DDPM):
                           'empty_context': self.empty_context, 'capture_distill_attn': False}
             return (emb, prompts, extra_info)
         # prompts (list of str) or token ids (int64 [B, 77]): the reference's flow, ddpm.py:966-1069
-        if zs_clip_features is not None or zs_id_embs is not None or apply_arc2face_inverse_embs or apply_arc2face_embs:
-            raise NotImplementedError("zero-shot identity conditioning (Arc2Face / SubjBasisGenerator) is not built: "
-                                      "SURVEY.md §8f-4, weight-blocked offline")
+        if apply_arc2face_inverse_embs or apply_arc2face_embs:
+            raise NotImplementedError("apply_arc2face_(inverse_)embs replace the prompt embeddings in training-time iterations "
+                                      "(ddpm.py:1010-1053): not part of the inference path")
+        if zs_clip_features is not None or zs_id_embs is not None:          # ddpm.py:992-999
+            if not getattr(self.embedding_manager, "do_zero_shot", False):
+                raise NotImplementedError("zero-shot identity conditioning needs an EmbeddingManager built with do_zero_shot=True "
+                                          "(plus the Arc2Face encoder and SubjBasisGenerator weights, absent offline)")
+            self.embedding_manager.set_zs_image_features(zs_clip_features, zs_id_embs, zs_out_id_embs_scale_range)
         if self.cond_stage_model is None:
             raise RuntimeError("this LatentDiffusion was built without a cond_stage_config: pass an embedding tensor")
         self.cond_stage_model.device = self.device

@@ -52,8 +52,8 @@ class StaticLayerwiseEmbedding(nn.Module):
         self.out_emb_dim = self.basis_vecs.shape[-1]
 
     def forward(self, static_zs_embs=None):
-        if static_zs_embs is not None:
-            raise NotImplementedError("zero-shot basis generation is not built (SURVEY.md §8f-4)")
+        if static_zs_embs is not None:       # zero-shot (:507-514): [BS, 16, K, D] -> [(BS 16), K, D], nothing learned here
+            return static_zs_embs.reshape(-1, *static_zs_embs.shape[2:])
         w = self.basis_rand_weights + self.basis_comm_weights                                     # :503
         vecs = self.basis_vecs if self.pre_vecs is None else torch.cat([self.pre_vecs, self.basis_vecs], dim=1)   # :517-521
         D = self.out_emb_dim
@@ -78,11 +78,20 @@ class EmbeddingManager(nn.Module):
                  layer_idx2ca_layer_idx=None, use_conv_attn_kernel_size=-1, do_zero_shot=False,
                  num_vectors_per_subj_token=1, **kwargs):
         super().__init__()
-        if do_zero_shot:
-            raise NotImplementedError("EmbeddingManager(do_zero_shot=True): the zero-shot identity path needs the Arc2Face / "
-                                      "SubjBasisGenerator weights, which do not exist offline (SURVEY.md §8f-4)")
         object.__setattr__(self, "text_embedder", text_embedder)      # not a submodule: the tower owns its own weights
-        self.do_zero_shot = False
+        # zero-shot identity path (embedding_manager.py:1406-1441, face subjects at inference): the
+        # subject's 16 x K embeddings are GENERATED per call from an ArcFace embedding: arc2face_text_encoder (a
+        # CLIPTextModelWrapper, "passed from ddpm.py", :1098-1100) -> one SubjBasisGenerator per placeholder.  Neither has
+        # weights offline; both are built random-init and take state dicts.  PARITY UNPINNED for the manager-side plumbing.
+        self.do_zero_shot = bool(do_zero_shot)
+        self.string_to_subj_basis_generator_dict = nn.ModuleDict()
+        self.arc2face_text_encoder = None
+        self.zs_image_feat_dict = {}
+        self.zs_out_id_embs_scale_range = (1.0, 1.0)
+        self.zs_arc2face_inverse_prompt_embs_inf_type = kwargs.get("zs_arc2face_inverse_prompt_embs_inf_type", "full_half_pad")
+        self.zs_tokenizer = kwargs.get("tokenizer", None)
+        self.zs_arc2face_input_ids = kwargs.get("zs_arc2face_input_ids", None)     # ids of "photo of a id person" [1, 77]
+        self.zs_arcface_token_id = kwargs.get("zs_arcface_token_id", None)
         self.use_layerwise_embedding = use_layerwise_embedding
         self.num_unet_ca_layers = num_unet_ca_layers
         self.num_layers_per_embedder = num_unet_ca_layers if use_layerwise_embedding else 1
@@ -116,8 +125,57 @@ class EmbeddingManager(nn.Module):
     def set_conv_attn_kernel_size(self, use_conv_attn_kernel_size=-1):   # :1759-1775
         self.use_conv_attn_kernel_size = -1 if use_conv_attn_kernel_size is None else use_conv_attn_kernel_size
 
-    def set_zs_image_features(self, *args, **kwargs):
-        raise NotImplementedError("zero-shot image features: SURVEY.md §8f-4, not built")
+    def set_zs_image_features(self, zs_clip_features, zs_id_embs, zs_out_id_embs_scale_range=(1.0, 1.0),
+                              add_noise_to_zs_id_embs=False):                      # :1786-1808 (inference: no noise)
+        if zs_clip_features is not None:
+            subj_feat, bg_feat = zs_clip_features.chunk(2, dim=1)
+        else:
+            subj_feat = bg_feat = None
+        self.zs_image_feat_dict = {'subj': subj_feat, 'bg': bg_feat, 'id': zs_id_embs}
+        self.zs_out_id_embs_scale_range = zs_out_id_embs_scale_range
+
+    def add_zero_shot_placeholder(self, string: str, token: int, num_vectors: int = 16, clip_config=None,
+                                  inverse_prompt_input_ids=None, pad_token_id=49407):
+        """A face subject whose embeddings come from a SubjBasisGenerator (:1163-1177)."""
+        from adaface_amd.ldm.modules.subj_basis_generator import SubjBasisGenerator
+        if not self.do_zero_shot:
+            raise RuntimeError("add_zero_shot_placeholder on an EmbeddingManager built with do_zero_shot=False")
+        self.string_to_token_dict[string] = int(token)
+        self.token2num_vectors[string] = num_vectors
+        if string not in self.placeholder_strings:
+            self.subject_strings.append(string)
+            self.subject_string_dict[string] = True
+            self.placeholder_strings = self.subject_strings + self.background_strings
+        self.string_to_subj_basis_generator_dict[string] = SubjBasisGenerator(
+            num_out_embs_per_layer=num_vectors, num_out_layers=self.num_unet_ca_layers, output_dim=self.out_emb_dim,
+            clip_config=clip_config, tokenizer=self.zs_tokenizer, inverse_prompt_input_ids=inverse_prompt_input_ids,
+            pad_token_id=pad_token_id)
+        self.curr_subj_is_face = True
+
+    def _zero_shot_embedding(self, string, device):
+        """:1406-1441: ArcFace [BS, 512] -> Arc2Face core identity embeddings -> SubjBasisGenerator -> [(BS 16), K, D]."""
+        from adaface_amd.ldm.util import arc2face_forward_face_embs
+        if string in self.background_string_dict:
+            raise NotImplementedError("zero-shot background placeholders are not built (SURVEY.md §8f-4)")
+        if self.arc2face_text_encoder is None:
+            raise RuntimeError("zero-shot: set embedding_manager.arc2face_text_encoder (a CLIPTextModelWrapper with the Arc2Face "
+                               "encoder's weights; the reference downloads 'arc2face/models', :1777-1784)")
+        zs_id_embs = self.zs_image_feat_dict.get('id')
+        if zs_id_embs is None:
+            raise RuntimeError("zero-shot: call set_zs_image_features(zs_clip_features, zs_id_embs) first")
+        zs_id_embs = zs_id_embs.to(device)
+        with torch.no_grad():
+            _, arc2face_id_embs = arc2face_forward_face_embs(self.zs_tokenizer, self.arc2face_text_encoder, zs_id_embs,
+                                                             return_full_and_core_embs=True,
+                                                             input_ids=self.zs_arc2face_input_ids,
+                                                             arcface_token_id=self.zs_arcface_token_id)
+            gen = self.string_to_subj_basis_generator_dict[string]
+            static_zs_embs, inverse_embs = gen(self.zs_image_feat_dict.get('subj'), zs_id_embs, arc2face_id_embs,
+                                               self.zs_out_id_embs_scale_range[0], is_face=self.curr_subj_is_face,
+                                               is_training=False,
+                                               arc2face_inverse_prompt_embs_inf_type=self.zs_arc2face_inverse_prompt_embs_inf_type)
+        self.arc2face_inverse_prompt_embs = inverse_embs
+        return static_zs_embs.reshape(-1, *static_zs_embs.shape[2:])              # StaticLayerwiseEmbedding.forward(:509)
 
     def extend_placeholders(self, new_subject_strings, new_background_strings, num_vectors_per_subj_token,
                             num_vectors_per_bg_token):
@@ -203,7 +261,11 @@ class EmbeddingManager(nn.Module):
                 continue
             rows, cols = extract_first_index_in_each_instance(idx)                           # :1366
             occurs = rows.numel() // self.num_layers_per_embedder                            # :1382
-            if string in self.string_to_static_embedder_dict:
+            if string in self.string_to_subj_basis_generator_dict:                          # :1406-1441 (zero-shot)
+                subj = self._zero_shot_embedding(string, device)
+                if subj.shape[0] < L * occurs and (L * occurs) % subj.shape[0] == 0 and subj.shape[0] != L:
+                    subj = subj.repeat((L * occurs) // subj.shape[0], 1, 1)                  # :1447-1449
+            elif string in self.string_to_static_embedder_dict:
                 subj = self.string_to_static_embedder_dict[string].to(device)(None)          # :1396, 1501
             else:
                 subj = self._static_tensors[string].to(device)                               # :1504-1505
@@ -215,6 +277,8 @@ class EmbeddingManager(nn.Module):
                 e_k = subj[:, k]
                 if e_k.shape[0] == L:
                     e_k = e_k.repeat(occurs, 1)
+                elif e_k.shape[0] != L * occurs:                                             # :1548-1549
+                    raise ValueError(f"placeholder '{string}': {e_k.shape[0]} embedding rows for {occurs} occurrences x {L} layers")
                 embedded_text[(rows, cols + k)] = e_k
             self.update_placeholder_indices(tokenized_text, string, token, K)
         self.update_prompt_masks(tokenized_text)                                             # :1324

@@ -106,6 +106,11 @@ int af_unet_forward(af_handle* h, const float* x_dev, const int64_t* t_dev, floa
 int af_clip_embed_tokens(af_handle* h, const int64_t* ids_dev, int64_t n, float* emb_dev, void* stream);
 int af_clip_text_forward(af_handle* h, const float* inputs_embeds_dev, int Bn, int T, float w_prev, float w_last,
                          float* out_dev, void* stream);
+/* the same with THREE blended hidden states (w_prev2 for the input of the second-to-last layer): CLIPTextModelWrapper.forward
+ * with hidden_state_layer_weights (ldm/modules/arc2face_models.py:230-243), the zero-shot identity path of SURVEY.md 8f-4
+ * (SubjBasisGenerator.prompt2token_proj, weights [1, 2, 4] / 7).  w_prev2 = w_prev = 0, w_last = 1: plain last state. */
+int af_clip_text_forward3(af_handle* h, const float* inputs_embeds_dev, int Bn, int T, float w_prev2, float w_prev, float w_last,
+                          float* out_dev, void* stream);
 
 /* Diagnostic tap on the U-Net's block outputs (what a forward hook on input_blocks[i] / middle_block / output_blocks[j]
  * of the reference UNetModel sees, openaimodel.py:984-1027): blocks are numbered in forward order, input_blocks

@@ -11,6 +11,11 @@ Pinning
     restatement is pinned against a RANDOMLY INITIALISED transformers.CLIPTextModel built from a config, driven the way
     the reference's patched forwards drive it (tests/golden/gen_golden_clip.py -> tests/golden/golden_clip.npz,
     tests/test_oracle_golden.py).
+  * zero-shot identity path: arc2face_forward_face_embs / arc2face_inverse_face_prompt_embs are the
+    reference's two drives of CLIPTextModelWrapper; their transformer arithmetic is pinned like clip_text_forward (plain
+    last state, and the last three states weighted [1, 2, 4] / 7; golden_clip.npz zs_*); subj_basis_generator_face and
+    the way the EmbeddingManager consumes it are restatements from the source text: PARITY UNPINNED (the module cannot be
+    imported offline and the real Arc2Face / AdaFace weights do not exist here).
   * embedding_manager_patch / static_layerwise_embedding — PARITY UNPINNED: ldm/modules/embedding_manager.py cannot be
     imported offline (its import of subj_basis_generator.py:22 fetches a tokenizer at import time) and the reference
     holds no fixture for it.  These are restatements from the source text, checked only for the properties the text
@@ -163,3 +168,55 @@ def embedding_manager_patch(ids: Tensor, emb: Tensor, token: int, subj_emb: Tens
         placeholder = None
     mask = ((ids != 49406) & (ids != 49407)).float().unsqueeze(2)
     return e, placeholder, mask
+
+
+# ----------------------------------------------------------------------------------------
+# zero-shot identity path
+# ----------------------------------------------------------------------------------------
+def arc2face_forward_face_embs(sd: SD, cfg: ClipConfig, input_ids: Tensor, id_token: int, face_embs: Tensor,
+                               prefix: str = CLIP_PREFIX):
+    """arc2face_forward_face_embs (ldm/util.py:1085-1131) on the Arc2Face text encoder (a CLIPTextModelWrapper,
+    arc2face_models.py:175-280): token embeddings of "photo of a id person" (input_ids [N, 77], the tokenizer's job), the
+    'id' token's embedding replaced by the ArcFace vector zero-padded to the hidden size (util.py:1111-1113), plain CLIP
+    forward (last hidden state -> final LayerNorm), full [N, 77, D] and core = tokens 4:20 (util.py:1126-1128)."""
+    tok = clip_embed_tokens(sd, input_ids, prefix).clone()
+    tok[input_ids == id_token] = F.pad(face_embs, (0, cfg.hidden - face_embs.shape[-1]))
+    full = clip_text_forward(sd, cfg, tok, skip_weights=(1.0,), prefix=prefix)
+    return full, full[:, 4:20]
+
+
+def clip_pad_embeddings(sd: SD, cfg: ClipConfig, pad_token: int, prefix: str = CLIP_PREFIX) -> Tensor:
+    """SubjBasisGenerator.generate_pad_embeddings (subj_basis_generator.py:583-596): CLIPTextEmbeddings of 77 pad tokens =
+    token_embedding[pad] + position_embedding: [77, D]."""
+    return sd[prefix + "embeddings.token_embedding.weight"][pad_token].unsqueeze(0) + \
+        sd[prefix + "embeddings.position_embedding.weight"][:cfg.max_pos]
+
+
+def arc2face_inverse_face_prompt_embs(sd: SD, cfg: ClipConfig, input_ids: Tensor, face_prompt_embs: Tensor,
+                                      pad_embeddings: Tensor, layer_weights=(1.0, 2.0, 4.0), prefix: str = CLIP_PREFIX):
+    """arc2face_inverse_face_prompt_embs without extra words (ldm/util.py:1138-1233) on prompt2token_proj: token embeddings of
+    "photo of a " + 16 ", " placeholders with positions 4:20 replaced by the core identity embeddings (:1186-1189), CLIP
+    forward blending the last len(layer_weights) hidden states (weights normalised to sum 1, arc2face_models.py:230-243),
+    core = tokens 4:20, and the 'full_half_pad' variant (:1213-1218: positions 24 .. 24 + (77 - 25) // 2 overwritten by the
+    pad embeddings)."""
+    tok = clip_embed_tokens(sd, input_ids, prefix).clone()
+    tok[:, 4:20] = face_prompt_embs
+    full = clip_text_forward(sd, cfg, tok, skip_weights=layer_weights, prefix=prefix)
+    half = full.clone()
+    pads = full.shape[1] - 25
+    if pads >= 2:
+        half[:, 24:24 + pads // 2] = pad_embeddings[24:24 + pads // 2]
+    return full, half, full[:, 4:20]
+
+
+def subj_basis_generator_face(sd: SD, cfg: ClipConfig, inverse_ids: Tensor, arc2face_id_embs: Tensor, pad_token: int,
+                              out_id_embs_scale: float = 1.0, n_layers: int = 16, layer_weights=(1.0, 2.0, 4.0),
+                              prefix: str = CLIP_PREFIX):
+    """SubjBasisGenerator.forward, the face / inference branch (subj_basis_generator.py:482-560): core identity embeddings
+    [BS, 16, D] from the inverse prompt forward, repeated over the 16 layers (:548-549), blended with pad embeddings 2 .. 2 + K
+    by out_id_embs_scale (:553-554).  Returns (static_zs_embs [BS, 16, K, D], 'full_half_pad' inverse prompt embeddings)."""
+    pad = clip_pad_embeddings(sd, cfg, pad_token, prefix)
+    _, half, core = arc2face_inverse_face_prompt_embs(sd, cfg, inverse_ids, arc2face_id_embs, pad, layer_weights, prefix)
+    K = core.shape[1]
+    out = core.unsqueeze(1).repeat(1, n_layers, 1, 1) * out_id_embs_scale + pad[2:2 + K].unsqueeze(0) * (1.0 - out_id_embs_scale)
+    return out, half

@@ -101,6 +101,39 @@ def main():
     z, _ = hf_forward(m, CO.clip_embed_tokens(sd, ids))
     out["sd15_ids"] = ids.numpy()
     out["sd15_z"] = z.numpy().astype(np.float32)
+    # ---- zero-shot identity path on tiny towers: two CLIPTextModel instances driven the way
+    # arc2face_forward_face_embs (ldm/util.py:1085-1131) and arc2face_inverse_face_prompt_embs (:1138-1233, called by
+    # SubjBasisGenerator.forward, subj_basis_generator.py:482-560) drive CLIPTextModelWrapper (arc2face_models.py:175-280):
+    # plain last hidden state for the first, the last THREE states weighted [1, 2, 4] / 7 for the second.  The prompts'
+    # token ids are stand-ins (no tokenizer offline): position 4 holds the 'id' token / positions 4..19 the placeholders.
+    cfg = CO.TINY_CLIP
+    g2 = torch.Generator().manual_seed(9)
+    sd_a = O.synth_state_dict(CO.clip_param_shapes(cfg), seed=43)      # "arc2face text encoder"
+    sd_p = O.synth_state_dict(CO.clip_param_shapes(cfg), seed=44)      # "prompt2token_proj"
+    m_a, m_p = hf_model(cfg, sd_a), hf_model(cfg, sd_p)
+    sd_t = O.synth_state_dict(CO.clip_param_shapes(cfg), seed=41)
+    m_t = hf_model(cfg, sd_t)
+    emb_t = CO.clip_embed_tokens(sd_t, torch.tensor(out["tiny_ids"]))
+    out["tiny_z_w1"] = hf_forward(m_t, emb_t, skip_weights=(1.0,))[0].numpy()
+    out["tiny_z_w124"] = hf_forward(m_t, emb_t, skip_weights=(1.0, 2.0, 4.0))[0].numpy()
+    id_dim, id_token, pad_token = 48, 333, 1
+    face = torch.randn(2, id_dim, generator=g2)
+    face = face / face.norm(dim=1, keepdim=True)
+    ids_a = torch.tensor([[0, 11, 12, 13, id_token, 14] + [pad_token] * 71])                 # "photo of a id person"
+    ids_a = ids_a.repeat(2, 1)
+    tok = CO.clip_embed_tokens(sd_a, ids_a).clone()
+    tok[ids_a == id_token] = torch.nn.functional.pad(face, (0, cfg.hidden - id_dim))
+    full_a, _ = hf_forward(m_a, tok, skip_weights=(1.0,))
+    core_a = full_a[:, 4:20]
+    ids_p = torch.tensor([[0, 11, 12, 13] + [15] * 16 + [pad_token] * 57]).repeat(2, 1)      # "photo of a , , ... ,"
+    tokp = CO.clip_embed_tokens(sd_p, ids_p).clone()
+    tokp[:, 4:20] = core_a
+    full_p, _ = hf_forward(m_p, tokp, skip_weights=(1.0, 2.0, 4.0))
+    out["zs_face"] = face.numpy()
+    out["zs_ids_arc2face"] = ids_a.numpy()
+    out["zs_ids_inverse"] = ids_p.numpy()
+    out["zs_arc2face_full"] = full_a.numpy()
+    out["zs_inverse_full"] = full_p.numpy()
     np.savez_compressed(ROOT / "tests" / "golden" / "golden_clip.npz", **out)
     for k, v in out.items():
         print(k, v.shape, v.dtype)

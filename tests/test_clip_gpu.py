@@ -118,3 +118,85 @@ def test_text_to_latent_pipeline_tiny(gpu, report):
     err = _rel(samples.cpu().numpy(), ref.numpy())
     report("token ids -> CLIP + EmbeddingManager -> 5-step DDIM latent vs chained oracles [f32]", err, float(ref.abs().max()), 1e-3)
     assert err < 1e-3, err
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# zero-shot identity path
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_clip_tower_three_state_blend_golden(gpu, report, dtype):
+    """af_clip_text_forward3: plain last state and the [1, 2, 4] / 7 blend of the last three hidden states
+    (CLIPTextModelWrapper.forward with hidden_state_layer_weights, arc2face_models.py:230-243) vs the transformers golden."""
+    from adaface_amd.engine import Engine
+    g = dict(np.load(GOLD / "golden_clip.npz"))
+    cfg = CO.TINY_CLIP
+    sd = O.synth_state_dict(CO.clip_param_shapes(cfg), seed=41)
+    eng = Engine(dtype=dtype, clip=_clip_kwargs(cfg))
+    assert eng.load_state_dict(sd) == []
+    emb = CO.clip_embed_tokens(sd, torch.tensor(g["tiny_ids"])).to(gpu)
+    for key, w in (("tiny_z_w1", (0.0, 0.0, 1.0)), ("tiny_z_w124", (1 / 7, 2 / 7, 4 / 7)), ("tiny_z", (0.0, 0.5, 0.5))):
+        z = eng.clip_text_forward3(emb, *w).cpu().numpy()
+        err = _rel(z, g[key])
+        report(f"clip tower three-state blend {key} vs transformers golden [{dtype}]", err, float(np.abs(g[key]).max()), TOL[dtype])
+        assert err < TOL[dtype], (key, err)
+    eng.close()
+
+
+def _load_wrapper(wrapper, sd):
+    missing, unexpected = wrapper.load_state_dict({k[len("cond_stage_model.transformer."):]: v for k, v in sd.items()}, strict=True)
+    assert not missing and not unexpected
+    return wrapper
+
+
+def test_zero_shot_identity_path_dropins(gpu, report):
+    """arc2face_forward_face_embs / arc2face_inverse_face_prompt_embs through the CLIPTextModelWrapper drop-in against the
+    transformers goldens (f32 mode), then SubjBasisGenerator and the EmbeddingManager's zero-shot branch against the CPU
+    oracle's restatement (parity unpinned for those two: they are compared with an independent restatement only)."""
+    from ldm.modules.arc2face_models import CLIPTextModelWrapper
+    from ldm.modules.embedding_manager import EmbeddingManager
+    from ldm.util import arc2face_forward_face_embs, arc2face_inverse_face_prompt_embs
+    g = dict(np.load(GOLD / "golden_clip.npz"))
+    cfg = CO.TINY_CLIP
+    kw = _clip_kwargs(cfg)
+    sd_a = O.synth_state_dict(CO.clip_param_shapes(cfg), seed=43)
+    sd_p = O.synth_state_dict(CO.clip_param_shapes(cfg), seed=44)
+    enc = _load_wrapper(CLIPTextModelWrapper(kw).set_compute_dtype("f32"), sd_a).to(gpu)
+    face = torch.tensor(g["zs_face"], device=gpu)
+    ids_a = torch.tensor(g["zs_ids_arc2face"][:1])
+    full, core = arc2face_forward_face_embs(None, enc, face, input_ids=ids_a, arcface_token_id=333)
+    err = _rel(full.cpu().numpy(), g["zs_arc2face_full"])
+    report("zero-shot: arc2face_forward_face_embs vs transformers golden [f32]", err, 1.0, TOL["f32"])
+    assert err < TOL["f32"] and core.shape == (2, 16, cfg.hidden)
+    p2t = _load_wrapper(CLIPTextModelWrapper(kw).set_compute_dtype("f32"), sd_p).to(gpu)
+    pad = CO.clip_pad_embeddings(sd_p, cfg, 1).to(gpu)
+    ids_p = torch.tensor(g["zs_ids_inverse"][:1])
+    full_p, core_p = arc2face_inverse_face_prompt_embs(None, p2t, torch.tensor(g["zs_arc2face_full"][:, 4:20], device=gpu), None,
+                                                       ["full", "core"], pad, hidden_state_layer_weights=torch.tensor([[1.0], [2.0], [4.0]]),
+                                                       input_ids=ids_p)
+    err = _rel(full_p.cpu().numpy(), g["zs_inverse_full"])
+    report("zero-shot: arc2face_inverse_face_prompt_embs vs transformers golden [f32]", err, 1.0, TOL["f32"])
+    assert err < TOL["f32"]
+
+    # ---- the manager's zero-shot branch: prompt ids with the placeholder, ArcFace vector in, patched embeddings out ----
+    token, K = 777, 16
+    man = EmbeddingManager(do_zero_shot=True, out_emb_dim=cfg.hidden, zs_arc2face_input_ids=ids_a, zs_arcface_token_id=333)
+    man.add_zero_shot_placeholder("z", token, K, clip_config=kw, inverse_prompt_input_ids=ids_p, pad_token_id=1)
+    gen = man.string_to_subj_basis_generator_dict["z"]
+    _load_wrapper(gen.prompt2token_proj.set_compute_dtype("f32"), sd_p)
+    man.arc2face_text_encoder = enc
+    man = man.to(gpu)
+    man.set_zs_image_features(None, face[:1], (0.75, 1.0))
+    gen_t = torch.Generator().manual_seed(3)
+    ids = torch.randint(2, cfg.vocab, (2, 77), generator=gen_t)
+    ids[:, 0] = 0
+    ids[0, 5] = token
+    ids[1, 9] = token
+    emb = torch.randn(2, 77, cfg.hidden, generator=gen_t)
+    out = man(ids.to(gpu), emb.to(gpu)).cpu()
+    # oracle: the same chain restated on the CPU
+    _, core_o = CO.arc2face_forward_face_embs(sd_a, cfg, ids_a, 333, torch.tensor(g["zs_face"][:1]))
+    zs, _ = CO.subj_basis_generator_face(sd_p, cfg, ids_p, core_o, 1, out_id_embs_scale=0.75)
+    ref, _, _ = CO.embedding_manager_patch(ids, emb, token, zs[0])
+    err = _rel(out.numpy(), ref.numpy())
+    report("zero-shot: EmbeddingManager(do_zero_shot) patched embeddings vs CPU restatement [f32]", err, 1.0, 1e-3)
+    assert out.shape == (32, 77, cfg.hidden) and err < 1e-3, err

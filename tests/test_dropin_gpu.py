@@ -208,7 +208,7 @@ def test_out_of_scope_branches_raise(gpu, tiny_model):
         tiny_model.apply_model(x, t, (emb, prompts, short))
     with pytest.raises(RuntimeError, match="vocabulary files are not available"):   # no tokenizer files offline
         tiny_model.get_learned_conditioning(["a photo of a z"])
-    with pytest.raises(NotImplementedError):                                         # zero-shot identity path: not built
+    with pytest.raises(NotImplementedError):                     # zero-shot conditioning on a manager built without it
         tiny_model.get_learned_conditioning(["a photo of a z"], zs_id_embs=torch.zeros(1, 512))
 
 

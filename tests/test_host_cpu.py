@@ -285,5 +285,11 @@ def test_embedding_manager_tensor_only_checkpoint(tmp_path):
     ids[0, 4] = 123
     out = em(ids, torch.zeros(1, 10, 8))
     assert torch.equal(out[7, 4:6], subj[7])
+    # zero-shot managers build but need the Arc2Face encoder and identity features before they can patch
+    zs = EmbeddingManager(None, subject_strings=[], do_zero_shot=True, out_emb_dim=8)
+    zs.add_zero_shot_placeholder("z", 123, 2, clip_config=dict(vocab=200, hidden=8, layers=2, heads=2, intermediate=16, max_pos=10))
+    with pytest.raises(RuntimeError, match="arc2face_text_encoder"):
+        zs(ids, torch.zeros(1, 10, 8))
     with pytest.raises(NotImplementedError):
-        EmbeddingManager(None, subject_strings=["z"], do_zero_shot=True)
+        from adaface_amd.ldm.modules.subj_basis_generator import SubjBasisGenerator
+        SubjBasisGenerator(placeholder_is_bg=True)

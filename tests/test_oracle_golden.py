@@ -236,3 +236,31 @@ def test_clip_oracle_matches_transformers_golden():
     z = CO.clip_text_forward(sd, cfg, CO.clip_embed_tokens(sd, torch.tensor(g["sd15_ids"])))
     assert np.abs(z.numpy() - g["sd15_z"]).max() < 5e-5 * np.abs(g["sd15_z"]).max()
     assert sum(int(np.prod(s)) for s in CO.clip_param_shapes(cfg).values()) == 123_060_480   # CLIP ViT-L/14 text tower
+
+
+def test_clip_oracle_zero_shot_identity_path_matches_transformers_golden():
+    """the two CLIP-tower drives of the zero-shot identity path (plain last state; last three states
+    weighted [1, 2, 4] / 7) against the randomly initialised transformers.CLIPTextModel of tests/golden/gen_golden_clip.py."""
+    import numpy as np
+    import torch
+    from oracle import clip_oracle as CO
+    from oracle import ldm_oracle as O
+    g = dict(np.load(GOLD / "golden_clip.npz"))
+    cfg = CO.TINY_CLIP
+    sd_t = O.synth_state_dict(CO.clip_param_shapes(cfg), seed=41)
+    emb = CO.clip_embed_tokens(sd_t, torch.tensor(g["tiny_ids"]))
+    for key, w in (("tiny_z_w1", (1.0,)), ("tiny_z_w124", (1.0, 2.0, 4.0))):
+        z = CO.clip_text_forward(sd_t, cfg, emb, skip_weights=w)
+        assert np.abs(z.numpy() - g[key]).max() < 2e-5 * max(1.0, np.abs(g[key]).max()), key
+    sd_a = O.synth_state_dict(CO.clip_param_shapes(cfg), seed=43)
+    sd_p = O.synth_state_dict(CO.clip_param_shapes(cfg), seed=44)
+    full_a, core = CO.arc2face_forward_face_embs(sd_a, cfg, torch.tensor(g["zs_ids_arc2face"]), 333, torch.tensor(g["zs_face"]))
+    assert np.abs(full_a.numpy() - g["zs_arc2face_full"]).max() < 2e-5 * np.abs(g["zs_arc2face_full"]).max()
+    pad = CO.clip_pad_embeddings(sd_p, cfg, 1)
+    full_p, half, core_p = CO.arc2face_inverse_face_prompt_embs(sd_p, cfg, torch.tensor(g["zs_ids_inverse"]), core, pad)
+    assert np.abs(full_p.numpy() - g["zs_inverse_full"]).max() < 2e-5 * np.abs(g["zs_inverse_full"]).max()
+    # properties of the un-pinned generator restatement: shape, layer copies identical at scale 1, pads at scale 0
+    zs, half2 = CO.subj_basis_generator_face(sd_p, cfg, torch.tensor(g["zs_ids_inverse"]), core, 1, out_id_embs_scale=1.0)
+    assert zs.shape == (2, 16, 16, cfg.hidden) and torch.equal(zs[:, 0], zs[:, 7]) and torch.allclose(zs[:, 3], core_p)
+    zs0, _ = CO.subj_basis_generator_face(sd_p, cfg, torch.tensor(g["zs_ids_inverse"]), core, 1, out_id_embs_scale=0.0)
+    assert torch.allclose(zs0[1, 5], pad[2:18]) and torch.equal(half2[:, 24:50], pad[24:50].expand(2, -1, -1))
