@@ -1523,6 +1523,212 @@ __global__ __launch_bounds__(512) void conv3x3_halo8_kernel(const ConvGemmParams
 }
 
 // ---------------------------------------------------------------------------
+// Row-panel GEGLU GEMM for K = 320 (FeedForward.net[0] of the 64x64-level transformers: [65536, 320] x [2560, 320]^T, 5 per
+// forward): a workgroup owns 256 rows for ALL of N.
+//
+// On the tiled kernel these launches are 5120 workgroups of five K steps each, and the prologue / epilogue around so short
+// a loop is most of their time (~500 TFLOP/s).  Here the activation rows never touch LDS: each wave keeps its 32 rows x 320
+// K values as MFMA B fragments in 80 VGPRs for the whole launch, and only the weight tiles stream (128 packed columns x
+// 64 K = 16 pieces per step, two per wave) through a three-slot LDS ring that runs on across the twenty column tiles --
+// no pipeline refill between tiles.  Per step a wave issues 2 LDS-DMA pieces, 16 fragment reads and 32 MFMAs; after
+// every fifth step the 32 x 64 GEGLU outputs of the wave go straight from the accumulators to HBM (8-byte buffer stores
+// that are ALWAYS issued -- rows past M by an out-of-range offset -- so the vmcnt arithmetic of the staging stays exact:
+// stores and LDS-DMA share that counter on gfx9).
+// LNMODE 1: LayerNorm-consumer epilogue as conv_gemm_pp_kernel (the rows are the un-normalised activations).
+// ---------------------------------------------------------------------------
+struct RowPanelCfg {
+  static constexpr int BM = 256, BN = 128, KC = 5, K = KC * 64;
+  static constexpr int WBYTES = BN * 128, LDS_BYTES = 3 * WBYTES;
+  static constexpr int NIW = BN / 16, MJ = 2;      // weight blocks per column tile, 16-row blocks per wave
+  static constexpr int NST = (NIW / 2) * MJ;       // buffer stores per wave and column tile
+};
+
+template <int LNMODE>
+__global__ __launch_bounds__(512) void geglu_rowpanel_kernel(const ConvGemmParams p) {
+  using C = RowPanelCfg;
+  typedef bf16 T;
+  constexpr int KC = C::KC, NIW = C::NIW, MJ = C::MJ, NST = C::NST;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * C::BM;
+  const int r0 = m0 + wid * 32;
+  const int ntn = p.N / C::BN;                     // packed column tiles (value | gate interleaved in 16-row groups)
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(reinterpret_cast<const T*>(p.src)), 0, (int)0xFFFFFFF0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(reinterpret_cast<const T*>(p.W)), 0, (int)0xFFFFFFF0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(p.out), 0, (int)0xFFFFFFF0u, 0x00020000);
+
+  // ---- the wave's 32 activation rows as MFMA B fragments: block j, K chunk kc, half u -> k = 64 kc + 32 u + 8 (lane >> 4) ----
+  pp_u32x4 xr[MJ][KC][2];
+  unsigned orow[MJ];                               // byte offset of the lane's output row (out-of-range when the row is)
+  float ln_mu[LNMODE == 1 ? MJ : 1], ln_rs[LNMODE == 1 ? MJ : 1];
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    const int m = r0 + j * 16 + (lane & 15);
+    const bool ok = m < p.M;
+    const unsigned xo = ok ? (unsigned)((long)m * p.ldc * 2) + (unsigned)(lane >> 4) * 16u : 0xFFFFFFFFu;
+    orow[j] = ok ? (unsigned)((long)m * p.ldo * 2) : 0xFFFFFFFFu;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        xr[j][kc][u] = __builtin_bit_cast(pp_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xo, (kc * 64 + u * 32) * 2, 0));
+    if constexpr (LNMODE == 1) {
+      float2 st = float2{0.f, 0.f};
+      if (ok) st = *reinterpret_cast<const float2*>(p.ln_stats + (long)m * 2);
+      ln_mu[j] = st.x;
+      ln_rs[j] = st.y;
+    }
+  }
+
+  // ---- weight staging: tile (nt, kc) = rows nt * 128 .. + 127 of W, bytes kc * 128 .. + 127 of each; piece = 8 rows ----
+  const int srow = lane >> 3;
+  const unsigned dchunk = (unsigned)((lane & 7) ^ srow);
+  unsigned w_off[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) w_off[q] = (unsigned)(((wid + 8 * q) * 8 + srow) * p.ldw * 2) + dchunk * 16u;
+  const int T_all = ntn * KC;
+  const unsigned tile_stride = (unsigned)(C::BN * p.ldw * 2);
+  auto stage = [&](int t, int slot) {              // (by value: see KWalk)
+    const int nt = t / KC, kc = t - nt * KC;
+    const bool live = t < T_all;
+    const unsigned so = (unsigned)nt * tile_stride + (unsigned)kc * 128u;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      lds_dma16(rs_w, smem + slot * C::WBYTES + (wid + 8 * q) * 1024, live ? w_off[q] : 0xFFFFFFFFu, so);
+  };
+
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) char*)smem);
+  const unsigned fch0 = (unsigned)((lane >> 4) ^ (lane & 7)) * 16u;
+  const unsigned fch1 = (unsigned)(((lane >> 4) + 4) ^ (lane & 7)) * 16u;
+  const unsigned w_base = (unsigned)((lane & 15) * 128);
+  const int cl = 4 * (lane >> 4);
+
+#ifdef AF_LAB_ABLATE
+  const int lab = p.fast_taps >> 4;   // timing ablations (wrong results): 1 no LDS-DMA, 2 no fragment reads, 4 no MFMAs, 8 no epilogue
+#else
+  constexpr int lab = 0;
+#endif
+  f32x4 acc[NIW][MJ];
+  pp_u32x4 wf[NIW][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < NIW; ++i)
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
+  auto wait_block = [&](auto nc, pp_u32x4 (&blk)[2]) {
+    constexpr int n = decltype(nc)::value;
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(blk[0]), "+v"(blk[1]) : "n"(n) : "memory");
+  };
+  // one K step of one column tile: weight blocks read two ahead of their MFMAs, counted waits; DMA for step t + 2
+  auto step = [&](auto kcc, int slot, int t, int stage_slot) {
+    constexpr int kc = decltype(kcc)::value;
+    const unsigned b0 = lds0 + (unsigned)(slot * C::WBYTES) + w_base + fch0;
+    const unsigned b1 = lds0 + (unsigned)(slot * C::WBYTES) + w_base + fch1;
+    auto rd = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if (lab & 2) return;
+      wf[i][0] = pp_lds_read128<i * 2048>(b0);
+      wf[i][1] = pp_lds_read128<i * 2048>(b1);
+    };
+    rd(std::integral_constant<int, 0>{});
+    rd(std::integral_constant<int, 1>{});
+    rd(std::integral_constant<int, 2>{});
+    __builtin_amdgcn_sched_barrier(0);
+    pp_static_for<0, NIW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int issued = (i + 3) < NIW ? (i + 3) : NIW;          // blocks issued before block i's MFMAs
+      wait_block(std::integral_constant<int, 2 * (issued - i - 1)>{}, wf[i]);
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) {
+        if (lab & 4) continue;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i][0]), __builtin_bit_cast(bf16x8, xr[j][kc][0]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i][1]), __builtin_bit_cast(bf16x8, xr[j][kc][1]), acc[i][j], 0, 0, 0);
+        asm volatile("" : "+v"(acc[i][j]));
+      }
+      if constexpr (i + 3 < NIW) rd(std::integral_constant<int, i + 3>{});
+      if constexpr (i == 1) { if (!(lab & 1)) stage(t + 2, stage_slot); }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    pp_wait_lgkm0();
+  };
+
+  // ---- main loop: steps t = (column tile, K chunk); tiles 0 / 1 of the ring in flight ----
+  stage(0, 0);
+  stage(1, 1);
+  int s0 = 0, s1 = 1, s2 = 2;
+  int after_epi = 0;                               // heads that still see the previous tile's stores in the counter
+  for (int nt = 0; nt < ntn; ++nt) {
+    pp_static_for<0, KC>([&](auto kcc) {
+      constexpr int kc = decltype(kcc)::value;
+      // own pieces of this step landed: everything but the two pieces of the next step (and, for two heads after an
+      // epilogue, its NST stores, which are YOUNGER than the pieces waited for)
+      if (after_epi > 0) { pp_wait_vm<2 + NST>(); --after_epi; } else pp_wait_vm<2>();
+      __builtin_amdgcn_s_barrier();
+      step(kcc, s0, nt * KC + kc, s2);
+      const int tmp = s0; s0 = s1; s1 = s2; s2 = tmp;
+    });
+    // ---- epilogue of the column tile: GEGLU of (value block 2 k2, gate block 2 k2 + 1), straight to HBM ----
+    // (every bias / column-sum vector of the tile is fetched first: one memory round trip, not one per block pair)
+    if (lab & 8) continue;
+    const int ncol = nt * (C::BN / 2);             // first output column of the tile
+    float4 bvec[NIW], cvec[LNMODE == 1 ? NIW : 1];
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+      bvec[i] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nt * C::BN + i * 16 + cl) : float4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (LNMODE == 1) cvec[i] = *reinterpret_cast<const float4*>(p.ln_colsum + nt * C::BN + i * 16 + cl);
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < NIW / 2; ++k2) {
+      const float* bvp = reinterpret_cast<const float*>(&bvec[2 * k2]);
+      const float* bgp = reinterpret_cast<const float*>(&bvec[2 * k2 + 1]);
+      const float* cvp = reinterpret_cast<const float*>(&cvec[LNMODE == 1 ? 2 * k2 : 0]);
+      const float* cgp = reinterpret_cast<const float*>(&cvec[LNMODE == 1 ? 2 * k2 + 1 : 0]);
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) {
+        Quad<T> o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float val, gat;
+          if constexpr (LNMODE == 1) {
+            val = (acc[2 * k2][j][e] - ln_mu[j] * cvp[e]) * ln_rs[j] + bvp[e];
+            gat = (acc[2 * k2 + 1][j][e] - ln_mu[j] * cgp[e]) * ln_rs[j] + bgp[e];
+          } else {
+            val = acc[2 * k2][j][e] * p.alpha + bvp[e];
+            gat = acc[2 * k2 + 1][j][e] * p.alpha + bgp[e];
+          }
+          o.e[e] = from_f32<T>(val * gelu_bf16out_f(gat));
+        }
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, o), rs_o, orow[j], (ncol + k2 * 16 + cl) * 2, 0);
+      }
+    }
+    zero_acc();
+    after_epi = 2;
+  }
+  pp_wait_vm<0>();
+}
+
+static int launch_geglu_rowpanel(const ConvGemmParams& p, hipStream_t stream) {
+  using C = RowPanelCfg;
+  dim3 grid((p.M + C::BM - 1) / C::BM, 1, 1);
+  if (p.ln_stats) {
+    static unsigned long long a1 = 0;
+    if (int rc = af_ensure_dynamic_lds(a1, reinterpret_cast<const void*>(&geglu_rowpanel_kernel<1>), C::LDS_BYTES)) return rc;
+    hipLaunchKernelGGL((geglu_rowpanel_kernel<1>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  } else {
+    static unsigned long long a0 = 0;
+    if (int rc = af_ensure_dynamic_lds(a0, reinterpret_cast<const void*>(&geglu_rowpanel_kernel<0>), C::LDS_BYTES)) return rc;
+    hipLaunchKernelGGL((geglu_rowpanel_kernel<0>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  }
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with an LDS-resident input halo.
 //
 // The implicit-GEMM kernel above re-gathers every input pixel 9 times (once per filter tap); at the 64x64 and
@@ -1893,8 +2099,8 @@ AfGemmPlan g_af_last_plan = {0, 1, 0, 0, 1};
 // launches since af_gemm_plan_counts_reset: [0..5] by tile (implicit-GEMM / ping-pong kernels), [6] LDS-halo kernel,
 // [7] launches that sliced K (counted in their tile's slot as well), [8] / [9] ping-pong launches with the LayerNorm
 // consumer / statistics-producer epilogue, [10] ping-pong launches with fp8 operands, [11] eight-wave halo launches
-// (counted under tile 5 as well)
-long g_af_plan_counts[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+// (counted under tile 5 as well), [12] row-panel GEGLU launches (counted under their planned tile as well)
+long g_af_plan_counts[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 
 // tile: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64
@@ -2263,6 +2469,15 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   if ((p.ln_stats || p.ln_stats_out) && !(pl.tile >= 4 && !pl.halo_tw)) {
     af_set_error_msg("conv_gemm: LayerNorm-fused launch planned on a kernel without that epilogue (tile %d)", pl.tile);
     return -1;
+  }
+  // GEGLU over K = 320 with enough rows for one workgroup per CU: the row-panel kernel (activations in registers)
+  if constexpr (sizeof(T) == 2) {
+    if (p.epilogue == AF_EPI_GEGLU && g_af_knobs.geglu_rowpanel && batch == 1 && p.ks == 1 && p.pad == 0 && p.stride == 1 &&
+        p.up == 0 && p.K == RowPanelCfg::K && p.Cin == RowPanelCfg::K && p.N % RowPanelCfg::BN == 0 && p.splitk <= 1 &&
+        p.M >= 128 * RowPanelCfg::BM && !p.residual && !p.rowbias && !p.ln_stats_out && p.ldc >= p.Cin) {
+      g_af_plan_counts[12] += 1;
+      return launch_geglu_rowpanel(p, stream);
+    }
   }
   if (pl.halo_tw == 256) {
     if constexpr (sizeof(T) == 2) {

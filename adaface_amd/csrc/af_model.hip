@@ -52,7 +52,7 @@ AfKnobs g_af_knobs = {
     knob_env("AF_GEMM_SPLITK", -1),    knob_env("AF_GEMM_GROUPM", -1),    knob_env("AF_GEMM_DMA", -1),
     knob_env("AF_PP_DIRECT", -1),      knob_env("AF_ATTN_W4", 1),         knob_env("AF_ATTN_RING", 1),
     knob_env("AF_GN_SMALL", 1),        knob_env("AF_GN_FOLD", 1),         knob_env("AF_CONV_TAP_INNER", 1),
-    knob_env("AF_LN_FUSE", 1),         knob_env("AF_CONV_HALO8", 1), knob_env("AF_CONV_FAST_TAPS", 1),
+    knob_env("AF_LN_FUSE", 1),         knob_env("AF_GEGLU_ROWPANEL", 1), knob_env("AF_CONV_HALO8", 1), knob_env("AF_CONV_FAST_TAPS", 1),
     knob_env("AF_PP_STAGGER", 1),
     knob_env("AF_PP_SCHED", 2)};
 static const AfKnobs g_af_knobs_initial = g_af_knobs;
@@ -63,7 +63,7 @@ static int* knob_slot(const char* name) {
       {"gemm_tile", &AfKnobs::gemm_tile}, {"gemm_splitk", &AfKnobs::gemm_splitk}, {"gemm_groupm", &AfKnobs::gemm_groupm},
       {"gemm_dma", &AfKnobs::gemm_dma}, {"pp_direct", &AfKnobs::pp_direct}, {"attn_w4", &AfKnobs::attn_w4}, {"attn_ring", &AfKnobs::attn_ring},
       {"gn_small", &AfKnobs::gn_small}, {"gn_fold", &AfKnobs::gn_fold}, {"conv_tap_inner", &AfKnobs::conv_tap_inner}, {"ln_fuse", &AfKnobs::ln_fuse},
-      {"conv_halo8", &AfKnobs::conv_halo8}, {"conv_fast_taps", &AfKnobs::conv_fast_taps}, {"pp_stagger", &AfKnobs::pp_stagger}, {"pp_sched", &AfKnobs::pp_sched}};
+      {"geglu_rowpanel", &AfKnobs::geglu_rowpanel}, {"conv_halo8", &AfKnobs::conv_halo8}, {"conv_fast_taps", &AfKnobs::conv_fast_taps}, {"pp_stagger", &AfKnobs::pp_stagger}, {"pp_sched", &AfKnobs::pp_sched}};
   if (!name) return nullptr;
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) return &(g_af_knobs.*(t.m));
@@ -1971,11 +1971,12 @@ int af_gemm_plan_counts(int64_t* counts10) {
   return AF_OK;
 }
 int af_gemm_plan_counts_reset(void) {
-  for (int i = 0; i < 12; ++i) g_af_plan_counts[i] = 0;
+  for (int i = 0; i < 13; ++i) g_af_plan_counts[i] = 0;
   return AF_OK;
 }
 int64_t af_fp8_gemm_launches(void) { return g_af_plan_counts[10]; }
 int64_t af_halo8_launches(void) { return g_af_plan_counts[11]; }
+int64_t af_rowpanel_launches(void) { return g_af_plan_counts[12]; }
 int af_set_fp8(af_handle* h, int on) {
   if (!h) { af_set_error_msg("af_set_fp8: null handle"); return AF_ERR_INVALID; }
   if (on && h->dtype != AF_DTYPE_BF16) { af_set_error_msg("af_set_fp8: the fp8 convolutions extend the bf16 mode (handle is f32)"); return AF_ERR_STATE; }

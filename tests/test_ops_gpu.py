@@ -174,6 +174,31 @@ def test_conv2d_pingpong(gpu, report, knobs, B, Cin, H, W, Cout, ks, stride, up,
     _cmp(report, f"pp conv{ks}x{ks} {Cin}->{Cout}@{H}x{W} s{stride} up{int(up)} sk{splitk}", got, ref, dtype)
 
 
+@pytest.mark.parametrize("M,N,bias", [(32768, 1280, True), (32868, 640, False), (65536, 1280, True)])
+def test_geglu_rowpanel(gpu, report, knobs, M, N, bias):
+    """GEGLU over K = 320 on the row-panel kernel (activation rows resident in registers, weight tiles streaming across all
+    column tiles) against torch and against the tiled eight-wave kernel on the same inputs (same K order: bit-identical).
+    M = 32868 leaves a last workgroup with 100 of its 256 rows (stores of the missing rows go out of range)."""
+    from adaface_amd import _lib, ops
+    g = torch.Generator().manual_seed(M + N)
+    K = 320
+    x = _q(torch.randn(M, K, generator=g), "bf16")
+    w = _q(torch.randn(2 * N, K, generator=g) / math.sqrt(K), "bf16")
+    b = torch.randn(2 * N, generator=g) * 0.1 if bias else None
+    ref = F.linear(x, w, b)
+    val, gate = ref.chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    args = (x.to(gpu), w.to(gpu), None if b is None else b.to(gpu))
+    _lib.plan_counts(reset=True)
+    got = ops.linear(*args, geglu=True, dtype="bf16")
+    assert _lib.plan_counts(reset=True)["rowpanel"] == 1
+    _cmp(report, f"row-panel geglu [{M},320]->{N}", got, ref, "bf16")
+    knobs("geglu_rowpanel", 0)
+    tiled = ops.linear(*args, geglu=True, dtype="bf16")
+    assert _lib.plan_counts(reset=True)["rowpanel"] == 0
+    assert torch.equal(got, tiled), (got - tiled).abs().max().item()
+
+
 @pytest.mark.parametrize("B,Cin,H,W,Cout,bias,res,splitk", [
     (2, 320, 64, 64, 320, True, True, 1),      # the dominant ResBlock conv: 4-row tiles of a 64-wide image, 5 chunks (odd K)
     (1, 64, 64, 64, 160, True, False, 1),      # one chunk: the prologue's halo only
