@@ -160,6 +160,27 @@ __device__ __forceinline__ float gelu_bf16out_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
 }
 
+// The same for PAIRS of values, without transcendentals: Phi(x) ~ 0.5 + xc q(xc^2), xc = x clamped to +-4, q a degree-6
+// minimax-weighted fit (max |error| of x Phi(x): 1.9e-4 over all x).  Written on 2-wide vectors so that hipcc emits the packed
+// f32 instructions (v_pk_mul_f32 / v_pk_fma_f32: two values per instruction at full rate): 9 packed + 2 v_med3 per PAIR
+// instead of 2 x (6 plain + v_exp + v_rcp, the last two quarter-rate) -- the GEGLU epilogue is VALU-bound (half of the
+// row-panel kernel's time, scripts/lab/ablate_conv.sh geglu).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_bf16out_f2(f32x2 x) {
+  f32x2 xc;
+  xc.x = __builtin_amdgcn_fmed3f(x.x, -4.0f, 4.0f);
+  xc.y = __builtin_amdgcn_fmed3f(x.y, -4.0f, 4.0f);
+  const f32x2 s = xc * xc;
+  f32x2 q = s * 2.27794120e-08f + (-1.59850396e-06f);
+  q = q * s + 4.79536935e-05f;
+  q = q * s + (-8.13999317e-04f);
+  q = q * s + 8.77231965e-03f;
+  q = q * s + (-6.45729896e-02f);
+  q = q * s + 3.97883296e-01f;
+  const f32x2 ph = xc * q + 0.5f;
+  return x * ph;
+}
+
 // ---------------------------------------------------------------------------
 // MFMA wrapper: one "fragment step" consumes a 16-byte fragment per lane from
 // each operand (= 32 bytes of K per row: 16 bf16 or 8 float).

@@ -520,16 +520,21 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
 #pragma unroll
         for (int j = 0; j < MI; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float val, gat;
-            if constexpr (LNMODE == 1) {
-              val = (acc[2 * k2][j][e] - ln_mu[j] * reinterpret_cast<const float*>(&ln_cs[2 * k2])[e]) * ln_rs[j] + bvp[e];
-              gat = (acc[2 * k2 + 1][j][e] - ln_mu[j] * reinterpret_cast<const float*>(&ln_cs[2 * k2 + 1])[e]) * ln_rs[j] + bgp[e];
-            } else {
-              val = acc[2 * k2][j][e] * p.alpha + bvp[e];
-              gat = acc[2 * k2 + 1][j][e] * p.alpha + bgp[e];
+          for (int e = 0; e < 4; e += 2) {      // pairs: the packed f32 instructions do two values each
+            f32x2 val, gat;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              if constexpr (LNMODE == 1) {
+                val[h] = (acc[2 * k2][j][e + h] - ln_mu[j] * reinterpret_cast<const float*>(&ln_cs[2 * k2])[e + h]) * ln_rs[j] + bvp[e + h];
+                gat[h] = (acc[2 * k2 + 1][j][e + h] - ln_mu[j] * reinterpret_cast<const float*>(&ln_cs[2 * k2 + 1])[e + h]) * ln_rs[j] + bgp[e + h];
+              } else {
+                val[h] = acc[2 * k2][j][e + h] * p.alpha + bvp[e + h];
+                gat[h] = acc[2 * k2 + 1][j][e + h] * p.alpha + bgp[e + h];
+              }
             }
-            acc[k2][j][e] = val * gelu_bf16out_f(gat);   // block k2 <= 2 k2: already consumed
+            const f32x2 r = val * gelu_bf16out_f2(gat);
+            acc[k2][j][e] = r.x;                 // block k2 <= 2 k2: already consumed
+            acc[k2][j][e + 1] = r.y;
           }
       }
     }
@@ -1531,16 +1536,20 @@ __global__ __launch_bounds__(512) void conv3x3_halo8_kernel(const ConvGemmParams
 // K values as MFMA B fragments in 80 VGPRs for the whole launch, and only the weight tiles stream (128 packed columns x
 // 64 K = 16 pieces per step, two per wave) through a three-slot LDS ring that runs on across the twenty column tiles --
 // no pipeline refill between tiles.  Per step a wave issues 2 LDS-DMA pieces, 16 fragment reads and 32 MFMAs; after
-// every fifth step the 32 x 64 GEGLU outputs of the wave go straight from the accumulators to HBM (8-byte buffer stores
-// that are ALWAYS issued -- rows past M by an out-of-range offset -- so the vmcnt arithmetic of the staging stays exact:
-// stores and LDS-DMA share that counter on gfx9).
+// every fifth step the 32 x 64 GEGLU outputs of the wave are transposed through a wave-private LDS tile and leave as four
+// 16-byte buffer stores of whole 128-byte row segments (8-byte stores straight from the accumulators -- 32 bytes per row and
+// instruction -- made the stores, not the GELU arithmetic, the cost of the epilogue).  The stores are ALWAYS issued -- rows
+// past M by an out-of-range offset -- so the vmcnt arithmetic of the staging stays exact: stores and LDS-DMA share that
+// counter on gfx9.
 // LNMODE 1: LayerNorm-consumer epilogue as conv_gemm_pp_kernel (the rows are the un-normalised activations).
 // ---------------------------------------------------------------------------
 struct RowPanelCfg {
   static constexpr int BM = 256, BN = 128, KC = 5, K = KC * 64;
-  static constexpr int WBYTES = BN * 128, LDS_BYTES = 3 * WBYTES;
+  static constexpr int WBYTES = BN * 128;
   static constexpr int NIW = BN / 16, MJ = 2;      // weight blocks per column tile, 16-row blocks per wave
-  static constexpr int NST = (NIW / 2) * MJ;       // buffer stores per wave and column tile
+  static constexpr int OPITCH = 144, OBYTES = 32 * OPITCH;   // per-wave output transposition tile: 32 rows x 128 B (+16 pad)
+  static constexpr int LDS_BYTES = 3 * WBYTES + 8 * OBYTES;
+  static constexpr int NST = 4;                    // 16-byte buffer stores per wave and column tile (8 rows x 128 B each)
 };
 
 template <int LNMODE>
@@ -1561,14 +1570,18 @@ __global__ __launch_bounds__(512) void geglu_rowpanel_kernel(const ConvGemmParam
 
   // ---- the wave's 32 activation rows as MFMA B fragments: block j, K chunk kc, half u -> k = 64 kc + 32 u + 8 (lane >> 4) ----
   pp_u32x4 xr[MJ][KC][2];
-  unsigned orow[MJ];                               // byte offset of the lane's output row (out-of-range when the row is)
+  unsigned orow[NST];                              // store mapping: row 8 i + (lane >> 3), 16-byte chunk lane & 7 of its segment
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int m = r0 + 8 * i + (lane >> 3);
+    orow[i] = m < p.M ? (unsigned)((long)m * p.ldo * 2) + (unsigned)(lane & 7) * 16u : 0xFFFFFFFFu;
+  }
   float ln_mu[LNMODE == 1 ? MJ : 1], ln_rs[LNMODE == 1 ? MJ : 1];
 #pragma unroll
   for (int j = 0; j < MJ; ++j) {
     const int m = r0 + j * 16 + (lane & 15);
     const bool ok = m < p.M;
     const unsigned xo = ok ? (unsigned)((long)m * p.ldc * 2) + (unsigned)(lane >> 4) * 16u : 0xFFFFFFFFu;
-    orow[j] = ok ? (unsigned)((long)m * p.ldo * 2) : 0xFFFFFFFFu;
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
@@ -1610,6 +1623,7 @@ __global__ __launch_bounds__(512) void geglu_rowpanel_kernel(const ConvGemmParam
 #else
   constexpr int lab = 0;
 #endif
+  char* otile = smem + 3 * C::WBYTES + wid * C::OBYTES;
   f32x4 acc[NIW][MJ];
   pp_u32x4 wf[NIW][2];
   auto zero_acc = [&]() {
@@ -1691,20 +1705,30 @@ __global__ __launch_bounds__(512) void geglu_rowpanel_kernel(const ConvGemmParam
       for (int j = 0; j < MJ; ++j) {
         Quad<T> o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float val, gat;
-          if constexpr (LNMODE == 1) {
-            val = (acc[2 * k2][j][e] - ln_mu[j] * cvp[e]) * ln_rs[j] + bvp[e];
-            gat = (acc[2 * k2 + 1][j][e] - ln_mu[j] * cgp[e]) * ln_rs[j] + bgp[e];
-          } else {
-            val = acc[2 * k2][j][e] * p.alpha + bvp[e];
-            gat = acc[2 * k2 + 1][j][e] * p.alpha + bgp[e];
+        for (int e = 0; e < 4; e += 2) {
+          f32x2 val, gat;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if constexpr (LNMODE == 1) {
+              val[h] = (acc[2 * k2][j][e + h] - ln_mu[j] * cvp[e + h]) * ln_rs[j] + bvp[e + h];
+              gat[h] = (acc[2 * k2 + 1][j][e + h] - ln_mu[j] * cgp[e + h]) * ln_rs[j] + bgp[e + h];
+            } else {
+              val[h] = acc[2 * k2][j][e + h] * p.alpha + bvp[e + h];
+              gat[h] = acc[2 * k2 + 1][j][e + h] * p.alpha + bgp[e + h];
+            }
           }
-          o.e[e] = from_f32<T>(val * gelu_bf16out_f(gat));
+          const f32x2 r = val * gelu_bf16out_f2(gat);
+          o.e[e] = from_f32<T>(r.x);
+          o.e[e + 1] = from_f32<T>(r.y);
         }
-        typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, o), rs_o, orow[j], (ncol + k2 * 16 + cl) * 2, 0);
+        o.store(reinterpret_cast<T*>(otile + (j * 16 + (lane & 15)) * C::OPITCH) + k2 * 16 + cl);
       }
+    }
+    // (wave-private tile: no barrier; the reads below are ordinary LDS loads, hipcc orders them after the writes)
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const pp_u32x4 v = *reinterpret_cast<const pp_u32x4*>(otile + (8 * i + (lane >> 3)) * C::OPITCH + (lane & 7) * 16);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, orow[i], ncol * 2, 0);
     }
     zero_acc();
     after_epi = 2;
