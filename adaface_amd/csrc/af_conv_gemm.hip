@@ -570,6 +570,25 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
     // within +-1 %, so it is the default for those two and AF_PP_DIRECT = 0 / 1 forces either.
     const int nblk = geglu ? NI / 2 : NI;
     const int cbase = ncol0 + g * HNo + cl;
+    // bf16 outputs leave through a WAVE-PRIVATE LDS tile (64 rows x HNo columns, no barriers) as 16-byte stores of whole
+    // row segments: straight from the accumulators a store instruction covers 32 bytes of each of 16 rows, and that
+    // pattern, not the arithmetic, was the cost of this epilogue (row-panel GEGLU: 160 -> 110 us from this change alone)
+    const int wpitch = HNo * 2 + 16;                  // bytes; 80 / 144 / 176: 8-byte writes of 16 rows hit distinct banks
+    char* wtile = smem + (g * 4 + wq) * (64 * (C::HN * 2 + 16));
+    auto wput = [&](int j, int i, const Quad<T>& o) { o.store(reinterpret_cast<T*>(wtile + (j * 16 + (lane & 15)) * wpitch) + i * 16 + cl); };
+    auto wflush = [&]() {
+      const int cpr = HNo >> 3;                       // 16-byte chunks per row segment (4 / 8 / 10)
+      const int total = 64 * cpr;
+#pragma unroll
+      for (int t = 0; t < C::HN / 8; ++t) {
+        const int c = lane + 64 * t;
+        if (c >= total) break;
+        const int row = c / cpr, ch = c - row * cpr;
+        const int m = m0 + wq * 64 + row;
+        const uint4 v = *reinterpret_cast<const uint4*>(wtile + row * wpitch + ch * 16);
+        if (m < p.M) *reinterpret_cast<uint4*>(out + (long)m * p.ldo + ncol0 + g * HNo + ch * 8) = v;
+      }
+    };
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
       const int m = m0 + wq * 64 + j * 16 + (lane & 15);
@@ -601,7 +620,7 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
             ps += vr;
             pq += vr * vr;
           }
-          if (mok) o.store(out + (long)m * p.ldo + cbase + i * 16);
+          wput(j, i, o);
         }
         ps += __shfl_xor(ps, 16, 64); pq += __shfl_xor(pq, 16, 64);
         ps += __shfl_xor(ps, 32, 64); pq += __shfl_xor(pq, 32, 64);
@@ -609,20 +628,21 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
           *reinterpret_cast<float2*>(p.ln_stats_out + ((long)(tn * 2 + g) * p.M + m) * 2) = float2{ps, pq};
         continue;
       }
-      if (m >= p.M) continue;
       if (slab) {
+        if (m >= p.M) continue;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
           if (i < nblk) *reinterpret_cast<f32x4*>(slab + (long)m * p.N + cbase + i * 16) = acc[i][j];
         continue;
       }
+      const bool mok2 = m < p.M;
       Quad<T> rq[NI], bq[NI];
-      if (rowb) {
+      if (rowb && mok2) {
         const T* rp = rowb + (long)(p.howo_shift >= 0 ? m >> p.howo_shift : m / HoWo) * p.ldrb + cbase;
 #pragma unroll
         for (int i = 0; i < NI; ++i) if (i < nblk) bq[i].load(rp + i * 16);
       }
-      if (res) {
+      if (res && mok2) {
         const T* rp = res + (long)m * p.ldr + cbase;
 #pragma unroll
         for (int i = 0; i < NI; ++i) if (i < nblk) rq[i].load(rp + i * 16);
@@ -634,13 +654,14 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = acc[i][j][e];
-          if (rowb) v += to_f32<T>(bq[i].e[e]);
-          if (res) v += to_f32<T>(rq[i].e[e]);
+          if (rowb && mok2) v += to_f32<T>(bq[i].e[e]);
+          if (res && mok2) v += to_f32<T>(rq[i].e[e]);
           o.e[e] = from_f32<T>(v);
         }
-        o.store(out + (long)m * p.ldo + cbase + i * 16);
+        wput(j, i, o);
       }
     }
+    if (!slab) wflush();
     return;
   }
   constexpr int ITEMS = BN / 32;                    // 8-column vectors per thread and pass (GEGLU: half of them)
