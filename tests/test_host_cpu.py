@@ -210,6 +210,26 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     assert "WORLD_SIZE=2" in (r.stderr + r.stdout)
 
 
+def test_identity_context_places_the_padded_id_vector_in_rows_4_to_19():
+    """BASELINE config 4's synthetic context: one unit-norm 512-d identity vector per sample, zero-padded to
+    768 (util.py:1111), in rows 4..19 of EVERY layer copy; the other rows are the plain prompt context."""
+    from adaface_amd.synth import synth_context, synth_context_identity
+    c = synth_context_identity(3, seed=100, device="cpu").reshape(3, 16, 77, 768)
+    base = synth_context(3, seed=100, device="cpu").reshape(3, 16, 77, 768)
+    assert torch.equal(c[:, :, :4], base[:, :, :4]) and torch.equal(c[:, :, 20:], base[:, :, 20:])
+    ident = c[:, 0, 4]
+    assert (c[:, :, 4:20] == ident[:, None, None, :]).all()          # the same vector in all 16 rows of all 16 layers
+    assert (ident[:, 512:] == 0).all() and torch.allclose(ident[:, :512].norm(dim=1), torch.full((3,), 512 ** 0.5))
+    assert not torch.equal(ident[0], ident[1])                        # a different identity per sample
+
+
+def test_bench_config4_plumbing_is_strong_scaling_batch_64():
+    """`bench.py --workload config4` (identity context, fp8 mode, global batch 64 in micro-batches) through the stubbed path."""
+    r, j = _run_bench(["--gpus", "1", "--workload", "config4", "--plumbing-test", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert j["config"]["global_batch"] == 64 and j["scaling"] == "strong" and "identity" in j["config"]["workload"]
+
+
 def test_adaprompt_context_differs_per_layer_only_in_subject_rows():
     from adaface_amd.synth import synth_context, synth_context_adaprompt
     c = synth_context_adaprompt(3, seed=100, device="cpu").reshape(3, 16, 77, 768)
