@@ -75,6 +75,7 @@ _SIGS = [
     ("af_last_gemm_plan", C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("af_prof_collect", C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]),
+    ("af_prof_event_overhead_us", C.c_double, [_P, C.c_int]),
     ("af_unet_num_blocks", C.c_int, [_P]),
     ("af_unet_block_shape", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("af_unet_set_tap", C.c_int, [_P, C.c_int, _P]),

@@ -1983,6 +1983,20 @@ int af_set_fp8(af_handle* h, int on) {
   h->fp8_on = on != 0;
   return AF_OK;
 }
+double af_prof_event_overhead_us(void* stream, int n) {
+  // what an event pair with NOTHING between its two records measures on this stream (the cost the bracket itself adds to
+  // every timed launch): bench.py subtracts it so that its per-kernel averages can be held against a rocprofv3 trace
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (n <= 0) n = 32;
+  std::vector<hipEvent_t> ev(2 * (size_t)n);
+  for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -1.0;
+  for (int i = 0; i < n; ++i) { hipEventRecord(ev[2 * i], s); hipEventRecord(ev[2 * i + 1], s); }
+  if (hipStreamSynchronize(s) != hipSuccess) return -1.0;
+  double tot = 0.0;
+  for (int i = 0; i < n; ++i) { float ms = 0.f; hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]); tot += ms; }
+  for (auto& e : ev) hipEventDestroy(e);
+  return 1e3 * tot / n;
+}
 int af_prof_collect(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes) {
   for (int c = 0; c < n_classes; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; bytes[c] = 0; }
   for (auto& r : g_prof_recs) {

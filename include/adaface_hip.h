@@ -168,6 +168,8 @@ int af_prof_reset(void);
  * bench.py samples (every = 7) inside its timed region; sums and launch counts then cover the sampled launches. */
 int af_prof_set_stride(int every);
 int af_prof_collect(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes);
+/* microseconds an EMPTY event pair measures on `stream` (mean of n): the bracket's own cost inside every timed launch */
+double af_prof_event_overhead_us(void* stream, int n);
 /* diagnostics: the tiling the most recent conv / linear launch of this process used.
  * tile: 0-3 = 128x128 / 64x128 / 128x64 / 64x64 four-wave tiles, 4 / 5 = 256x128 / 256x160 eight-wave ping-pong tiles;
  * halo_tw != 0: LDS-halo 3x3 kernel.  The parity tests use it to assert which kernel they exercised. */
