@@ -1564,25 +1564,34 @@ __global__ __launch_bounds__(512) void conv3x3_halo8_kernel(const ConvGemmParams
 // counter on gfx9.
 // LNMODE 1: LayerNorm-consumer epilogue as conv_gemm_pp_kernel (the rows are the un-normalised activations).
 // ---------------------------------------------------------------------------
-struct RowPanelCfg {
-  static constexpr int BM = 256, BN = 128, KC = 5, K = KC * 64;
-  static constexpr int WBYTES = BN * 128;
+// Generalised (round 2, later): GEGLU = false runs the other K = 320 GEMMs of the 64x64-level transformers on the same
+// structure with 160-column tiles -- proj_in / to_q,k,v / attn2.to_q / to_out / proj_out -- with the LayerNorm-consumer
+// (LNMODE 1) or statistics-producer (LNMODE 2) epilogue and the residual added in the accumulator layout (one rounding, as
+// the tiled kernel).
+template <bool GEGLU> struct RowPanelCfgT {
+  static constexpr int BM = 256, BN = GEGLU ? 128 : 160, KC = 5, K = KC * 64;
+  static constexpr int WBYTES = BN * 128, WPIECES = BN / 8;
   static constexpr int NIW = BN / 16, MJ = 2;      // weight blocks per column tile, 16-row blocks per wave
-  static constexpr int OPITCH = 144, OBYTES = 32 * OPITCH;   // per-wave output transposition tile: 32 rows x 128 B (+16 pad)
+  static constexpr int OCOLS = GEGLU ? BN / 2 : BN;                 // output columns per tile
+  static constexpr int OPITCH = OCOLS * 2 + 16, OBYTES = 32 * OPITCH;   // per-wave output transposition tile (bf16)
   static constexpr int LDS_BYTES = 3 * WBYTES + 8 * OBYTES;
-  static constexpr int NST = 4;                    // 16-byte buffer stores per wave and column tile (8 rows x 128 B each)
+  static constexpr int CPR = OCOLS / 8;            // 16-byte chunks per output row segment
+  static constexpr int NST = 32 * CPR / 64;        // 16-byte buffer stores per lane and column tile
+  static_assert(LDS_BYTES <= 160 * 1024 && (32 * CPR) % 64 == 0, "row-panel LDS / store mapping");
 };
+typedef RowPanelCfgT<true> RowPanelCfg;
 
-template <int LNMODE>
-__global__ __launch_bounds__(512) void geglu_rowpanel_kernel(const ConvGemmParams p) {
-  using C = RowPanelCfg;
+template <bool GEGLU, int LNMODE, bool RES>
+__global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
+  using C = RowPanelCfgT<GEGLU>;
   typedef bf16 T;
-  constexpr int KC = C::KC, NIW = C::NIW, MJ = C::MJ, NST = C::NST;
+  constexpr int KC = C::KC, NIW = C::NIW, MJ = C::MJ, NST = C::NST, CPR = C::CPR;
+  static_assert(!(GEGLU && (RES || LNMODE == 2)), "GEGLU: plain or LayerNorm-consumer epilogue, no residual");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * C::BM;
   const int r0 = m0 + wid * 32;
-  const int ntn = p.N / C::BN;                     // packed column tiles (value | gate interleaved in 16-row groups)
+  const int ntn = p.N / C::BN;                     // column tiles (GEGLU: value | gate interleaved in 16-row groups)
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<T*>(reinterpret_cast<const T*>(p.src)), 0, (int)0xFFFFFFF0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
@@ -1591,11 +1600,14 @@ __global__ __launch_bounds__(512) void geglu_rowpanel_kernel(const ConvGemmParam
 
   // ---- the wave's 32 activation rows as MFMA B fragments: block j, K chunk kc, half u -> k = 64 kc + 32 u + 8 (lane >> 4) ----
   pp_u32x4 xr[MJ][KC][2];
-  unsigned orow[NST];                              // store mapping: row 8 i + (lane >> 3), 16-byte chunk lane & 7 of its segment
+  // store mapping: chunk c = lane + 64 i of the wave's 32 x CPR chunks -> row c / CPR, 16-byte chunk c % CPR of its segment
+  unsigned orow[NST];
 #pragma unroll
   for (int i = 0; i < NST; ++i) {
-    const int m = r0 + 8 * i + (lane >> 3);
-    orow[i] = m < p.M ? (unsigned)((long)m * p.ldo * 2) + (unsigned)(lane & 7) * 16u : 0xFFFFFFFFu;
+    const int c = lane + 64 * i;
+    const int row = c / CPR, ch = c - row * CPR;
+    const int m = r0 + row;
+    orow[i] = m < p.M ? (unsigned)((long)m * p.ldo * 2) + (unsigned)ch * 16u : 0xFFFFFFFFu;
   }
   float ln_mu[LNMODE == 1 ? MJ : 1], ln_rs[LNMODE == 1 ? MJ : 1];
 #pragma unroll
@@ -1616,12 +1628,14 @@ __global__ __launch_bounds__(512) void geglu_rowpanel_kernel(const ConvGemmParam
     }
   }
 
-  // ---- weight staging: tile (nt, kc) = rows nt * 128 .. + 127 of W, bytes kc * 128 .. + 127 of each; piece = 8 rows ----
+  // ---- weight staging: tile (nt, kc) = rows nt * BN .. of W, bytes kc * 128 .. + 127 of each; piece = 8 rows ----
   const int srow = lane >> 3;
   const unsigned dchunk = (unsigned)((lane & 7) ^ srow);
-  unsigned w_off[2];
+  constexpr int NWQ = (C::WPIECES + 7) / 8;        // pieces per wave (2; 3 for waves 0-3 at BN = 160)
+  const int nwq = (C::WPIECES - wid + 7) / 8;
+  unsigned w_off[NWQ];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) w_off[q] = (unsigned)(((wid + 8 * q) * 8 + srow) * p.ldw * 2) + dchunk * 16u;
+  for (int q = 0; q < NWQ; ++q) w_off[q] = (unsigned)(((wid + 8 * q) * 8 + srow) * p.ldw * 2) + dchunk * 16u;
   const int T_all = ntn * KC;
   const unsigned tile_stride = (unsigned)(C::BN * p.ldw * 2);
   auto stage = [&](int t, int slot) {              // (by value: see KWalk)
@@ -1629,8 +1643,9 @@ __global__ __launch_bounds__(512) void geglu_rowpanel_kernel(const ConvGemmParam
     const bool live = t < T_all;
     const unsigned so = (unsigned)nt * tile_stride + (unsigned)kc * 128u;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-      lds_dma16(rs_w, smem + slot * C::WBYTES + (wid + 8 * q) * 1024, live ? w_off[q] : 0xFFFFFFFFu, so);
+    for (int q = 0; q < NWQ; ++q)
+      if (q < 2 || wid + 8 * q < C::WPIECES)
+        lds_dma16(rs_w, smem + slot * C::WBYTES + (wid + 8 * q) * 1024, live ? w_off[q] : 0xFFFFFFFFu, so);
   };
 
   const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) char*)smem);
@@ -1699,56 +1714,107 @@ __global__ __launch_bounds__(512) void geglu_rowpanel_kernel(const ConvGemmParam
   for (int nt = 0; nt < ntn; ++nt) {
     pp_static_for<0, KC>([&](auto kcc) {
       constexpr int kc = decltype(kcc)::value;
-      // own pieces of this step landed: everything but the two pieces of the next step (and, for two heads after an
-      // epilogue, its NST stores, which are YOUNGER than the pieces waited for)
-      if (after_epi > 0) { pp_wait_vm<2 + NST>(); --after_epi; } else pp_wait_vm<2>();
+      // own pieces of this step landed: everything but the pieces of the next step (and, for two heads after an epilogue,
+      // its NST stores, which are YOUNGER than the pieces waited for).  (BN = 160: waves 0-3 stage three pieces a step.)
+      if (after_epi > 0) {
+        if (nwq == 3) pp_wait_vm<3 + NST>(); else pp_wait_vm<2 + NST>();
+        --after_epi;
+      } else {
+        if (nwq == 3) pp_wait_vm<3>(); else pp_wait_vm<2>();
+      }
       __builtin_amdgcn_s_barrier();
       step(kcc, s0, nt * KC + kc, s2);
       const int tmp = s0; s0 = s1; s1 = s2; s2 = tmp;
     });
-    // ---- epilogue of the column tile: GEGLU of (value block 2 k2, gate block 2 k2 + 1), straight to HBM ----
-    // (every bias / column-sum vector of the tile is fetched first: one memory round trip, not one per block pair)
+    // ---- epilogue of the column tile (every bias / column-sum / residual vector is fetched first: one memory round trip) ----
     if (lab & 8) continue;
-    const int ncol = nt * (C::BN / 2);             // first output column of the tile
+    const int ncol = nt * C::OCOLS;                // first output column of the tile
     float4 bvec[NIW], cvec[LNMODE == 1 ? NIW : 1];
 #pragma unroll
     for (int i = 0; i < NIW; ++i) {
       bvec[i] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nt * C::BN + i * 16 + cl) : float4{0.f, 0.f, 0.f, 0.f};
       if constexpr (LNMODE == 1) cvec[i] = *reinterpret_cast<const float4*>(p.ln_colsum + nt * C::BN + i * 16 + cl);
     }
+    if constexpr (GEGLU) {
 #pragma unroll
-    for (int k2 = 0; k2 < NIW / 2; ++k2) {
-      const float* bvp = reinterpret_cast<const float*>(&bvec[2 * k2]);
-      const float* bgp = reinterpret_cast<const float*>(&bvec[2 * k2 + 1]);
-      const float* cvp = reinterpret_cast<const float*>(&cvec[LNMODE == 1 ? 2 * k2 : 0]);
-      const float* cgp = reinterpret_cast<const float*>(&cvec[LNMODE == 1 ? 2 * k2 + 1 : 0]);
+      for (int k2 = 0; k2 < NIW / 2; ++k2) {
+        const float* bvp = reinterpret_cast<const float*>(&bvec[2 * k2]);
+        const float* bgp = reinterpret_cast<const float*>(&bvec[2 * k2 + 1]);
+        const float* cvp = reinterpret_cast<const float*>(&cvec[LNMODE == 1 ? 2 * k2 : 0]);
+        const float* cgp = reinterpret_cast<const float*>(&cvec[LNMODE == 1 ? 2 * k2 + 1 : 0]);
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+          Quad<T> o;
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            f32x2 val, gat;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              if constexpr (LNMODE == 1) {
+                val[h] = (acc[2 * k2][j][e + h] - ln_mu[j] * cvp[e + h]) * ln_rs[j] + bvp[e + h];
+                gat[h] = (acc[2 * k2 + 1][j][e + h] - ln_mu[j] * cgp[e + h]) * ln_rs[j] + bgp[e + h];
+              } else {
+                val[h] = acc[2 * k2][j][e + h] * p.alpha + bvp[e + h];
+                gat[h] = acc[2 * k2 + 1][j][e + h] * p.alpha + bgp[e + h];
+              }
+            }
+            const f32x2 r = val * gelu_bf16out_f2(gat);
+            o.e[e] = from_f32<T>(r.x);
+            o.e[e + 1] = from_f32<T>(r.y);
+          }
+          o.store(reinterpret_cast<T*>(otile + (j * 16 + (lane & 15)) * C::OPITCH) + k2 * 16 + cl);
+        }
+      }
+    } else {
 #pragma unroll
       for (int j = 0; j < MJ; ++j) {
-        Quad<T> o;
+        const int m = r0 + j * 16 + (lane & 15);
+        const bool mok = m < p.M;
+        Quad<T> rq[RES ? NIW : 1];
+        if constexpr (RES) {
+          const T* rp = reinterpret_cast<const T*>(p.residual) + (long)(mok ? m : 0) * p.ldr + ncol + cl;
 #pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-          f32x2 val, gat;
+          for (int i = 0; i < NIW; ++i) rq[i].load(rp + i * 16);
+        }
+        float ps = 0.f, pq = 0.f;
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            if constexpr (LNMODE == 1) {
-              val[h] = (acc[2 * k2][j][e + h] - ln_mu[j] * cvp[e + h]) * ln_rs[j] + bvp[e + h];
-              gat[h] = (acc[2 * k2 + 1][j][e + h] - ln_mu[j] * cgp[e + h]) * ln_rs[j] + bgp[e + h];
-            } else {
-              val[h] = acc[2 * k2][j][e + h] * p.alpha + bvp[e + h];
-              gat[h] = acc[2 * k2 + 1][j][e + h] * p.alpha + bgp[e + h];
+        for (int i = 0; i < NIW; ++i) {
+          const float* bp = reinterpret_cast<const float*>(&bvec[i]);
+          const float* cp = reinterpret_cast<const float*>(&cvec[LNMODE == 1 ? i : 0]);
+          Quad<T> o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v;
+            if constexpr (LNMODE == 1) v = (acc[i][j][e] - ln_mu[j] * cp[e]) * ln_rs[j] + bp[e];
+            else v = acc[i][j][e] * p.alpha + bp[e];
+            if constexpr (RES) v += to_f32<T>(rq[i].e[e]);
+            o.e[e] = from_f32<T>(v);
+            if constexpr (LNMODE == 2) {
+              const float vr = mok ? to_f32<T>(o.e[e]) : 0.f;     // the value the consumer will read
+              ps += vr;
+              pq += vr * vr;
             }
           }
-          const f32x2 r = val * gelu_bf16out_f2(gat);
-          o.e[e] = from_f32<T>(r.x);
-          o.e[e + 1] = from_f32<T>(r.y);
+          o.store(reinterpret_cast<T*>(otile + (j * 16 + (lane & 15)) * C::OPITCH) + i * 16 + cl);
         }
-        o.store(reinterpret_cast<T*>(otile + (j * 16 + (lane & 15)) * C::OPITCH) + k2 * 16 + cl);
+        if constexpr (LNMODE == 2) {
+          // per-row partial sums of this 160-column tile: statistics slab 2 nt (slab 2 nt + 1, which the tiled kernel's
+          // second wave group would fill, is written as zero so that ln_finalize_kernel sums the same number of parts)
+          ps += __shfl_xor(ps, 16, 64); pq += __shfl_xor(pq, 16, 64);
+          ps += __shfl_xor(ps, 32, 64); pq += __shfl_xor(pq, 32, 64);
+          if (mok && (lane >> 4) == 0) {
+            *reinterpret_cast<float2*>(p.ln_stats_out + ((long)(2 * nt) * p.M + m) * 2) = float2{ps, pq};
+            *reinterpret_cast<float2*>(p.ln_stats_out + ((long)(2 * nt + 1) * p.M + m) * 2) = float2{0.f, 0.f};
+          }
+        }
       }
     }
     // (wave-private tile: no barrier; the reads below are ordinary LDS loads, hipcc orders them after the writes)
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
-      const pp_u32x4 v = *reinterpret_cast<const pp_u32x4*>(otile + (8 * i + (lane >> 3)) * C::OPITCH + (lane & 7) * 16);
+      const int c = lane + 64 * i;
+      const int row = c / CPR, ch = c - row * CPR;
+      const pp_u32x4 v = *reinterpret_cast<const pp_u32x4*>(otile + row * C::OPITCH + ch * 16);
       __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, orow[i], ncol * 2, 0);
     }
     zero_acc();
@@ -1757,20 +1823,23 @@ __global__ __launch_bounds__(512) void geglu_rowpanel_kernel(const ConvGemmParam
   pp_wait_vm<0>();
 }
 
-static int launch_geglu_rowpanel(const ConvGemmParams& p, hipStream_t stream) {
-  using C = RowPanelCfg;
+template <bool GEGLU, int LNMODE, bool RES> static int launch_rowpanel_one(const ConvGemmParams& p, hipStream_t stream) {
+  using C = RowPanelCfgT<GEGLU>;
+  static unsigned long long attr_done = 0;
+  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&rowpanel_kernel<GEGLU, LNMODE, RES>), C::LDS_BYTES)) return rc;
   dim3 grid((p.M + C::BM - 1) / C::BM, 1, 1);
-  if (p.ln_stats) {
-    static unsigned long long a1 = 0;
-    if (int rc = af_ensure_dynamic_lds(a1, reinterpret_cast<const void*>(&geglu_rowpanel_kernel<1>), C::LDS_BYTES)) return rc;
-    hipLaunchKernelGGL((geglu_rowpanel_kernel<1>), grid, dim3(512), C::LDS_BYTES, stream, p);
-  } else {
-    static unsigned long long a0 = 0;
-    if (int rc = af_ensure_dynamic_lds(a0, reinterpret_cast<const void*>(&geglu_rowpanel_kernel<0>), C::LDS_BYTES)) return rc;
-    hipLaunchKernelGGL((geglu_rowpanel_kernel<0>), grid, dim3(512), C::LDS_BYTES, stream, p);
-  }
+  hipLaunchKernelGGL((rowpanel_kernel<GEGLU, LNMODE, RES>), grid, dim3(512), C::LDS_BYTES, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
+}
+static int launch_geglu_rowpanel(const ConvGemmParams& p, hipStream_t stream) {
+  return p.ln_stats ? launch_rowpanel_one<true, 1, false>(p, stream) : launch_rowpanel_one<true, 0, false>(p, stream);
+}
+static int launch_plain_rowpanel(const ConvGemmParams& p, hipStream_t stream) {
+  const bool res = p.residual != nullptr;
+  if (p.ln_stats) return res ? launch_rowpanel_one<false, 1, true>(p, stream) : launch_rowpanel_one<false, 1, false>(p, stream);
+  if (p.ln_stats_out) return res ? launch_rowpanel_one<false, 2, true>(p, stream) : launch_rowpanel_one<false, 2, false>(p, stream);
+  return res ? launch_rowpanel_one<false, 0, true>(p, stream) : launch_rowpanel_one<false, 0, false>(p, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -2522,6 +2591,14 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
         p.M >= 128 * RowPanelCfg::BM && !p.residual && !p.rowbias && !p.ln_stats_out && p.ldc >= p.Cin) {
       g_af_plan_counts[12] += 1;
       return launch_geglu_rowpanel(p, stream);
+    }
+    // ... and the other K = 320 GEMMs of those transformers (N = 320 / 960), LayerNorm-consumer / -producer epilogue, residual
+    if (p.epilogue != AF_EPI_GEGLU && g_af_knobs.geglu_rowpanel >= 2 && batch == 1 && p.ks == 1 && p.pad == 0 && p.stride == 1 &&
+        p.up == 0 && p.K == RowPanelCfg::K && p.Cin == RowPanelCfg::K && p.N % 160 == 0 && p.splitk <= 1 && p.alpha == 1.0f &&
+        p.M >= 128 * RowPanelCfg::BM && !p.rowbias && !(p.ln_stats && p.ln_stats_out) && p.ldc >= p.Cin &&
+        (!p.residual || p.ldr % 4 == 0)) {
+      g_af_plan_counts[12] += 1;
+      return launch_plain_rowpanel(p, stream);
     }
   }
   if (pl.halo_tw == 256) {

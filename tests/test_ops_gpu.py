@@ -199,6 +199,32 @@ def test_geglu_rowpanel(gpu, report, knobs, M, N, bias):
     assert torch.equal(got, tiled), (got - tiled).abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,bias,res", [(32768, 320, True, True), (32868, 960, False, False), (65536, 320, True, False)])
+def test_plain_rowpanel(gpu, report, knobs, M, N, bias, res):
+    """The row-panel kernel on the non-GEGLU K = 320 GEMMs (160-column tiles, residual added in the accumulator layout):
+    against torch and, bit for bit, against the tiled eight-wave kernel."""
+    from adaface_amd import _lib, ops
+    knobs("geglu_rowpanel", 2)
+    g = torch.Generator().manual_seed(M + N + 5)
+    K = 320
+    x = _q(torch.randn(M, K, generator=g), "bf16")
+    w = _q(torch.randn(N, K, generator=g) / math.sqrt(K), "bf16")
+    b = torch.randn(N, generator=g) * 0.1 if bias else None
+    r = _q(torch.randn(M, N, generator=g), "bf16") if res else None
+    ref = F.linear(x, w, b)
+    if res:
+        ref = ref + r
+    args = (x.to(gpu), w.to(gpu), None if b is None else b.to(gpu), None if r is None else r.to(gpu))
+    _lib.plan_counts(reset=True)
+    got = ops.linear(*args, dtype="bf16")
+    assert _lib.plan_counts(reset=True)["rowpanel"] == 1
+    _cmp(report, f"row-panel linear [{M},320]->{N}", got, ref, "bf16")
+    knobs("geglu_rowpanel", 1)
+    tiled = ops.linear(*args, dtype="bf16")
+    assert _lib.plan_counts(reset=True)["rowpanel"] == 0
+    assert torch.equal(got, tiled), (got - tiled).abs().max().item()
+
+
 @pytest.mark.parametrize("B,Cin,H,W,Cout,bias,res,splitk", [
     (2, 320, 64, 64, 320, True, True, 1),      # the dominant ResBlock conv: 4-row tiles of a 64-wide image, 5 chunks (odd K)
     (1, 64, 64, 64, 160, True, False, 1),      # one chunk: the prologue's halo only
