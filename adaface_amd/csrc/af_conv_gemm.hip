@@ -1571,30 +1571,36 @@ __global__ __launch_bounds__(512) void conv3x3_halo8_kernel(const ConvGemmParams
 // structure with 160-column tiles -- proj_in / to_q,k,v / attn2.to_q / to_out / proj_out -- with the LayerNorm-consumer
 // (LNMODE 1) or statistics-producer (LNMODE 2) epilogue and the residual added in the accumulator layout (one rounding, as
 // the tiled kernel).
-template <bool GEGLU> struct RowPanelCfgT {
-  static constexpr int BM = 256, BN = GEGLU ? 128 : 160, KC = 5, K = KC * 64;
+// KC_ = 10, MJ_ = 1: the K = 640 form for the 32x32-level transformers (16 rows per wave keep the fragment registers at 80;
+// 128-row panels, and the column tiles of a panel split over gridDim.y workgroups so that 16384 rows still fill 256 CUs).
+template <bool GEGLU, int KC_ = 5, int MJ_ = 2> struct RowPanelCfgT {
+  static constexpr int KC = KC_, MJ = MJ_, K = KC * 64;
+  static constexpr int WROWS = 16 * MJ, BM = 8 * WROWS;             // rows per wave / per workgroup
+  static constexpr int BN = GEGLU ? 128 : 160;
   static constexpr int WBYTES = BN * 128, WPIECES = BN / 8;
-  static constexpr int NIW = BN / 16, MJ = 2;      // weight blocks per column tile, 16-row blocks per wave
+  static constexpr int NIW = BN / 16;              // weight blocks per column tile
   static constexpr int OCOLS = GEGLU ? BN / 2 : BN;                 // output columns per tile
-  static constexpr int OPITCH = OCOLS * 2 + 16, OBYTES = 32 * OPITCH;   // per-wave output transposition tile (bf16)
+  static constexpr int OPITCH = OCOLS * 2 + 16, OBYTES = WROWS * OPITCH;   // per-wave output transposition tile (bf16)
   static constexpr int LDS_BYTES = 3 * WBYTES + 8 * OBYTES;
   static constexpr int CPR = OCOLS / 8;            // 16-byte chunks per output row segment
-  static constexpr int NST = 32 * CPR / 64;        // 16-byte buffer stores per lane and column tile
-  static_assert(LDS_BYTES <= 160 * 1024 && (32 * CPR) % 64 == 0, "row-panel LDS / store mapping");
+  static constexpr int NST = WROWS * CPR / 64;     // 16-byte buffer stores per lane and column tile
+  static_assert(LDS_BYTES <= 160 * 1024 && (WROWS * CPR) % 64 == 0 && MJ * KC == 10, "row-panel LDS / store mapping / 80 fragment registers");
 };
 typedef RowPanelCfgT<true> RowPanelCfg;
 
-template <bool GEGLU, int LNMODE, bool RES>
+template <bool GEGLU, int LNMODE, bool RES, int KC_ = 5, int MJ_ = 2>
 __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
-  using C = RowPanelCfgT<GEGLU>;
+  using C = RowPanelCfgT<GEGLU, KC_, MJ_>;
   typedef bf16 T;
   constexpr int KC = C::KC, NIW = C::NIW, MJ = C::MJ, NST = C::NST, CPR = C::CPR;
   static_assert(!(GEGLU && (RES || LNMODE == 2)), "GEGLU: plain or LayerNorm-consumer epilogue, no residual");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * C::BM;
-  const int r0 = m0 + wid * 32;
-  const int ntn = p.N / C::BN;                     // column tiles (GEGLU: value | gate interleaved in 16-row groups)
+  const int r0 = m0 + wid * C::WROWS;
+  const int ntn_all = p.N / C::BN;                 // column tiles (GEGLU: value | gate interleaved in 16-row groups)
+  const int nt_begin = (int)((long)blockIdx.y * ntn_all / gridDim.y), nt_end = (int)((long)(blockIdx.y + 1) * ntn_all / gridDim.y);
+  const int ntn = nt_end - nt_begin;               // ... of this workgroup
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<T*>(reinterpret_cast<const T*>(p.src)), 0, (int)0xFFFFFFF0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
@@ -1642,9 +1648,9 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
   const int T_all = ntn * KC;
   const unsigned tile_stride = (unsigned)(C::BN * p.ldw * 2);
   auto stage = [&](int t, int slot) {              // (by value: see KWalk)
-    const int nt = t / KC, kc = t - nt * KC;
+    const int ntl = t / KC, kc = t - ntl * KC;
     const bool live = t < T_all;
-    const unsigned so = (unsigned)nt * tile_stride + (unsigned)kc * 128u;
+    const unsigned so = (unsigned)(nt_begin + ntl) * tile_stride + (unsigned)kc * 128u;
 #pragma unroll
     for (int q = 0; q < NWQ; ++q)
       if (q < 2 || wid + 8 * q < C::WPIECES)
@@ -1714,7 +1720,8 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
   stage(1, 1);
   int s0 = 0, s1 = 1, s2 = 2;
   int after_epi = 0;                               // heads that still see the previous tile's stores in the counter
-  for (int nt = 0; nt < ntn; ++nt) {
+  for (int ntl = 0; ntl < ntn; ++ntl) {
+    const int nt = nt_begin + ntl;
     pp_static_for<0, KC>([&](auto kcc) {
       constexpr int kc = decltype(kcc)::value;
       // own pieces of this step landed: everything but the pieces of the next step (and, for two heads after an epilogue,
@@ -1726,19 +1733,19 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
         if (nwq == 3) pp_wait_vm<3>(); else pp_wait_vm<2>();
       }
       __builtin_amdgcn_s_barrier();
-      step(kcc, s0, nt * KC + kc, s2);
+      step(kcc, s0, ntl * KC + kc, s2);
       const int tmp = s0; s0 = s1; s1 = s2; s2 = tmp;
     });
     // ---- epilogue of the column tile (every bias / column-sum / residual vector is fetched first: one memory round trip) ----
     if (lab & 8) continue;
     const int ncol = nt * C::OCOLS;                // first output column of the tile
-    float4 bvec[NIW], cvec[LNMODE == 1 ? NIW : 1];
-#pragma unroll
-    for (int i = 0; i < NIW; ++i) {
-      bvec[i] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nt * C::BN + i * 16 + cl) : float4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (LNMODE == 1) cvec[i] = *reinterpret_cast<const float4*>(p.ln_colsum + nt * C::BN + i * 16 + cl);
-    }
     if constexpr (GEGLU) {
+      float4 bvec[NIW], cvec[LNMODE == 1 ? NIW : 1];
+#pragma unroll
+      for (int i = 0; i < NIW; ++i) {
+        bvec[i] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nt * C::BN + i * 16 + cl) : float4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (LNMODE == 1) cvec[i] = *reinterpret_cast<const float4*>(p.ln_colsum + nt * C::BN + i * 16 + cl);
+      }
 #pragma unroll
       for (int k2 = 0; k2 < NIW / 2; ++k2) {
         const float* bvp = reinterpret_cast<const float*>(&bvec[2 * k2]);
@@ -1769,44 +1776,67 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
         }
       }
     } else {
+      // two halves of five 16-column blocks: the bias / column-sum / residual vectors of ten blocks next to 80 accumulator
+      // and 80 fragment registers do not fit 256 VGPRs (scratch traffic, and its vmcnt drains, in every epilogue)
+      constexpr int NH = NIW / 2;
+      static_assert(NIW % 2 == 0, "row-panel: even number of 16-column blocks");
+      float ps[MJ], pq[MJ];
 #pragma unroll
-      for (int j = 0; j < MJ; ++j) {
-        const int m = r0 + j * 16 + (lane & 15);
-        const bool mok = m < p.M;
-        Quad<T> rq[RES ? NIW : 1];
-        if constexpr (RES) {
-          const T* rp = reinterpret_cast<const T*>(p.residual) + (long)(mok ? m : 0) * p.ldr + ncol + cl;
+      for (int j = 0; j < MJ; ++j) ps[j] = pq[j] = 0.f;
 #pragma unroll
-          for (int i = 0; i < NIW; ++i) rq[i].load(rp + i * 16);
+      for (int hh = 0; hh < 2; ++hh) {
+        float4 bvec[NH], cvec[LNMODE == 1 ? NH : 1];
+#pragma unroll
+        for (int ii = 0; ii < NH; ++ii) {
+          const int i = hh * NH + ii;
+          bvec[ii] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nt * C::BN + i * 16 + cl) : float4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (LNMODE == 1) cvec[ii] = *reinterpret_cast<const float4*>(p.ln_colsum + nt * C::BN + i * 16 + cl);
         }
-        float ps = 0.f, pq = 0.f;
 #pragma unroll
-        for (int i = 0; i < NIW; ++i) {
-          const float* bp = reinterpret_cast<const float*>(&bvec[i]);
-          const float* cp = reinterpret_cast<const float*>(&cvec[LNMODE == 1 ? i : 0]);
-          Quad<T> o;
+        for (int j = 0; j < MJ; ++j) {
+          const int m = r0 + j * 16 + (lane & 15);
+          const bool mok = m < p.M;
+          Quad<T> rq[RES ? NH : 1];
+          if constexpr (RES) {
+            const T* rp = reinterpret_cast<const T*>(p.residual) + (long)(mok ? m : 0) * p.ldr + ncol + hh * NH * 16 + cl;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v;
-            if constexpr (LNMODE == 1) v = (acc[i][j][e] - ln_mu[j] * cp[e]) * ln_rs[j] + bp[e];
-            else v = acc[i][j][e] * p.alpha + bp[e];
-            if constexpr (RES) v += to_f32<T>(rq[i].e[e]);
-            o.e[e] = from_f32<T>(v);
-            if constexpr (LNMODE == 2) {
-              const float vr = mok ? to_f32<T>(o.e[e]) : 0.f;     // the value the consumer will read
-              ps += vr;
-              pq += vr * vr;
-            }
+            for (int ii = 0; ii < NH; ++ii) rq[ii].load(rp + ii * 16);
           }
-          o.store(reinterpret_cast<T*>(otile + (j * 16 + (lane & 15)) * C::OPITCH) + i * 16 + cl);
+#pragma unroll
+          for (int ii = 0; ii < NH; ++ii) {
+            const int i = hh * NH + ii;
+            const float* bp = reinterpret_cast<const float*>(&bvec[ii]);
+            const float* cp = reinterpret_cast<const float*>(&cvec[LNMODE == 1 ? ii : 0]);
+            Quad<T> o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v;
+              if constexpr (LNMODE == 1) v = (acc[i][j][e] - ln_mu[j] * cp[e]) * ln_rs[j] + bp[e];
+              else v = acc[i][j][e] * p.alpha + bp[e];
+              if constexpr (RES) v += to_f32<T>(rq[ii].e[e]);
+              o.e[e] = from_f32<T>(v);
+              if constexpr (LNMODE == 2) {
+                const float vr = mok ? to_f32<T>(o.e[e]) : 0.f;     // the value the consumer will read
+                ps[j] += vr;
+                pq[j] += vr * vr;
+              }
+            }
+            o.store(reinterpret_cast<T*>(otile + (j * 16 + (lane & 15)) * C::OPITCH) + i * 16 + cl);
+          }
         }
-        if constexpr (LNMODE == 2) {
-          // per-row partial sums of this 160-column tile: statistics slab 2 nt (slab 2 nt + 1, which the tiled kernel's
-          // second wave group would fill, is written as zero so that ln_finalize_kernel sums the same number of parts)
-          ps += __shfl_xor(ps, 16, 64); pq += __shfl_xor(pq, 16, 64);
-          ps += __shfl_xor(ps, 32, 64); pq += __shfl_xor(pq, 32, 64);
-          if (mok && (lane >> 4) == 0) {
-            *reinterpret_cast<float2*>(p.ln_stats_out + ((long)(2 * nt) * p.M + m) * 2) = float2{ps, pq};
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (LNMODE == 2) {
+        // per-row partial sums of this 160-column tile: statistics slab 2 nt (slab 2 nt + 1, which the tiled kernel's
+        // second wave group would fill, is written as zero so that ln_finalize_kernel sums the same number of parts)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+          const int m = r0 + j * 16 + (lane & 15);
+          float s1 = ps[j], s2 = pq[j];
+          s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+          s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+          if (m < p.M && (lane >> 4) == 0) {
+            *reinterpret_cast<float2*>(p.ln_stats_out + ((long)(2 * nt) * p.M + m) * 2) = float2{s1, s2};
             *reinterpret_cast<float2*>(p.ln_stats_out + ((long)(2 * nt + 1) * p.M + m) * 2) = float2{0.f, 0.f};
           }
         }
@@ -1826,20 +1856,29 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
   pp_wait_vm<0>();
 }
 
-template <bool GEGLU, int LNMODE, bool RES> static int launch_rowpanel_one(const ConvGemmParams& p, hipStream_t stream) {
-  using C = RowPanelCfgT<GEGLU>;
+template <bool GEGLU, int LNMODE, bool RES, int KC = 5, int MJ = 2>
+static int launch_rowpanel_one(const ConvGemmParams& p, hipStream_t stream) {
+  using C = RowPanelCfgT<GEGLU, KC, MJ>;
   static unsigned long long attr_done = 0;
-  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&rowpanel_kernel<GEGLU, LNMODE, RES>), C::LDS_BYTES)) return rc;
-  dim3 grid((p.M + C::BM - 1) / C::BM, 1, 1);
-  hipLaunchKernelGGL((rowpanel_kernel<GEGLU, LNMODE, RES>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&rowpanel_kernel<GEGLU, LNMODE, RES, KC, MJ>), C::LDS_BYTES)) return rc;
+  const int panels = (p.M + C::BM - 1) / C::BM, ntn = p.N / C::BN;
+  int ny = 1;                                       // column tiles of a panel over ny workgroups until ~256 exist
+  while (panels * ny < 192 && ny * 2 <= ntn && ntn % (ny * 2) == 0) ny *= 2;
+  dim3 grid(panels, ny, 1);
+  hipLaunchKernelGGL((rowpanel_kernel<GEGLU, LNMODE, RES, KC, MJ>), grid, dim3(512), C::LDS_BYTES, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-static int launch_geglu_rowpanel(const ConvGemmParams& p, hipStream_t stream) {
+// (k640: the 32x32-level form, K = 640, 16 rows per wave)
+static int launch_geglu_rowpanel(const ConvGemmParams& p, hipStream_t stream, bool k640 = false) {
+  if (k640) return p.ln_stats ? launch_rowpanel_one<true, 1, false, 10, 1>(p, stream) : launch_rowpanel_one<true, 0, false, 10, 1>(p, stream);
   return p.ln_stats ? launch_rowpanel_one<true, 1, false>(p, stream) : launch_rowpanel_one<true, 0, false>(p, stream);
 }
-static int launch_plain_rowpanel(const ConvGemmParams& p, hipStream_t stream) {
+static int launch_plain_rowpanel(const ConvGemmParams& p, hipStream_t stream, bool k640 = false) {
   const bool res = p.residual != nullptr;
+  if (k640) {   // (at K = 640 only the LayerNorm-consumer q / k / v projection is long enough to gain)
+    return p.ln_stats ? launch_rowpanel_one<false, 1, false, 10, 1>(p, stream) : launch_rowpanel_one<false, 0, false, 10, 1>(p, stream);
+  }
   if (p.ln_stats) return res ? launch_rowpanel_one<false, 1, true>(p, stream) : launch_rowpanel_one<false, 1, false>(p, stream);
   if (p.ln_stats_out) return res ? launch_rowpanel_one<false, 2, true>(p, stream) : launch_rowpanel_one<false, 2, false>(p, stream);
   return res ? launch_rowpanel_one<false, 0, true>(p, stream) : launch_rowpanel_one<false, 0, false>(p, stream);
@@ -2604,6 +2643,18 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
         (!p.residual || p.ldr % 4 == 0)) {
       g_af_plan_counts[12] += 1;
       return launch_plain_rowpanel(p, stream);
+    }
+    // K = 640 (32x32 level): GEGLU, and the q / k / v projection (N >= 1920: enough column tiles per workgroup)
+    if (g_af_knobs.geglu_rowpanel >= 3 && batch == 1 && p.ks == 1 && p.pad == 0 && p.stride == 1 && p.up == 0 && p.K == 640 &&
+        p.Cin == 640 && p.splitk <= 1 && p.M >= 16384 && !p.residual && !p.rowbias && !p.ln_stats_out && p.ldc >= p.Cin) {
+      if (p.epilogue == AF_EPI_GEGLU && p.N % 128 == 0) {
+        g_af_plan_counts[12] += 1;
+        return launch_geglu_rowpanel(p, stream, true);
+      }
+      if (p.epilogue != AF_EPI_GEGLU && p.N % 160 == 0 && p.N >= 1920 && p.alpha == 1.0f) {
+        g_af_plan_counts[12] += 1;
+        return launch_plain_rowpanel(p, stream, true);
+      }
     }
   }
   if (pl.halo_tw == 256) {

@@ -174,14 +174,15 @@ def test_conv2d_pingpong(gpu, report, knobs, B, Cin, H, W, Cout, ks, stride, up,
     _cmp(report, f"pp conv{ks}x{ks} {Cin}->{Cout}@{H}x{W} s{stride} up{int(up)} sk{splitk}", got, ref, dtype)
 
 
-@pytest.mark.parametrize("M,N,bias", [(32768, 1280, True), (32868, 640, False), (65536, 1280, True)])
-def test_geglu_rowpanel(gpu, report, knobs, M, N, bias):
-    """GEGLU over K = 320 on the row-panel kernel (activation rows resident in registers, weight tiles streaming across all
-    column tiles) against torch and against the tiled eight-wave kernel on the same inputs (same K order: bit-identical).
-    M = 32868 leaves a last workgroup with 100 of its 256 rows (stores of the missing rows go out of range)."""
+@pytest.mark.parametrize("M,K,N,bias", [(32768, 320, 1280, True), (32868, 320, 640, False), (65536, 320, 1280, True),
+                                        (16384, 640, 2560, True), (16434, 640, 192, False), (32768, 640, 2560, False)])
+def test_geglu_rowpanel(gpu, report, knobs, M, K, N, bias):
+    """GEGLU over K = 320 / 640 on the row-panel kernel (activation rows resident in registers, weight tiles streaming across
+    all column tiles) against torch and against the tiled eight-wave kernel on the same inputs (same K order: bit-identical).
+    M = 32868 leaves a last workgroup with 100 of its 256 rows (stores of the missing rows go out of range); K = 640 is the
+    16-rows-per-wave form whose column tiles are split over two workgroups per panel at 16384 rows (N = 192: three tiles, no split)."""
     from adaface_amd import _lib, ops
     g = torch.Generator().manual_seed(M + N)
-    K = 320
     x = _q(torch.randn(M, K, generator=g), "bf16")
     w = _q(torch.randn(2 * N, K, generator=g) / math.sqrt(K), "bf16")
     b = torch.randn(2 * N, generator=g) * 0.1 if bias else None
@@ -192,21 +193,22 @@ def test_geglu_rowpanel(gpu, report, knobs, M, N, bias):
     _lib.plan_counts(reset=True)
     got = ops.linear(*args, geglu=True, dtype="bf16")
     assert _lib.plan_counts(reset=True)["rowpanel"] == 1
-    _cmp(report, f"row-panel geglu [{M},320]->{N}", got, ref, "bf16")
+    _cmp(report, f"row-panel geglu [{M},{K}]->{N}", got, ref, "bf16")
     knobs("geglu_rowpanel", 0)
     tiled = ops.linear(*args, geglu=True, dtype="bf16")
     assert _lib.plan_counts(reset=True)["rowpanel"] == 0
     assert torch.equal(got, tiled), (got - tiled).abs().max().item()
 
 
-@pytest.mark.parametrize("M,N,bias,res", [(32768, 320, True, True), (32868, 960, False, False), (65536, 320, True, False)])
-def test_plain_rowpanel(gpu, report, knobs, M, N, bias, res):
-    """The row-panel kernel on the non-GEGLU K = 320 GEMMs (160-column tiles, residual added in the accumulator layout):
+@pytest.mark.parametrize("M,K,N,bias,res", [(32768, 320, 320, True, True), (32868, 320, 960, False, False), (65536, 320, 320, True, False),
+                                            (16384, 640, 1920, True, False), (16434, 640, 2400, False, False)])
+def test_plain_rowpanel(gpu, report, knobs, M, K, N, bias, res):
+    """The row-panel kernel on the non-GEGLU K = 320 GEMMs (160-column tiles, residual added in the accumulator layout) and
+    on the K = 640 q / k / v projection (N >= 1920; 2400 = 15 tiles, an odd count that stays on one workgroup per panel):
     against torch and, bit for bit, against the tiled eight-wave kernel."""
     from adaface_amd import _lib, ops
-    knobs("geglu_rowpanel", 2)
+    knobs("geglu_rowpanel", 3)
     g = torch.Generator().manual_seed(M + N + 5)
-    K = 320
     x = _q(torch.randn(M, K, generator=g), "bf16")
     w = _q(torch.randn(N, K, generator=g) / math.sqrt(K), "bf16")
     b = torch.randn(N, generator=g) * 0.1 if bias else None
@@ -218,7 +220,7 @@ def test_plain_rowpanel(gpu, report, knobs, M, N, bias, res):
     _lib.plan_counts(reset=True)
     got = ops.linear(*args, dtype="bf16")
     assert _lib.plan_counts(reset=True)["rowpanel"] == 1
-    _cmp(report, f"row-panel linear [{M},320]->{N}", got, ref, "bf16")
+    _cmp(report, f"row-panel linear [{M},{K}]->{N}", got, ref, "bf16")
     knobs("geglu_rowpanel", 1)
     tiled = ops.linear(*args, dtype="bf16")
     assert _lib.plan_counts(reset=True)["rowpanel"] == 0
