@@ -91,6 +91,7 @@ _SIGS = [
     ("af_fp8_gemm_launches", C.c_int64, []),
     ("af_halo8_launches", C.c_int64, []),
     ("af_rowpanel_launches", C.c_int64, []),
+    ("af_up_phase4_launches", C.c_int64, []),
     ("af_op_conv2d_fp8", C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 10 + [_P]),
     ("af_op_groupnorm_fp8", C.c_int, [_P, _P, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("af_op_layernorm_fp8", C.c_int, [_P, _P, _P, C.c_float, _P, C.c_int64, C.c_int, C.c_int, _P]),
@@ -145,6 +146,7 @@ def plan_counts(reset: bool = False) -> dict:
     out["fp8"] = int(lib.af_fp8_gemm_launches())
     out["halo8"] = int(lib.af_halo8_launches())
     out["rowpanel"] = int(lib.af_rowpanel_launches())
+    out["up_phase4"] = int(lib.af_up_phase4_launches())
     if reset:
         lib.af_gemm_plan_counts_reset()
     return out

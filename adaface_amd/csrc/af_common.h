@@ -88,6 +88,7 @@ struct AfKnobs {
   int conv_halo8;           // AF_CONV_HALO8           0 = 3x3 / stride-1 convs stay on the gathering eight-wave kernel (no LDS halo)
   int conv_fast_taps;       // AF_CONV_FAST_TAPS       0 = ping-pong convs recompute every tap's bounds check in the staging phase
   int pp_stagger;           // AF_PP_STAGGER           merged schedule: 1 = the two wave groups issue their LDS-DMA pieces behind alternate MFMAs
+  int conv_up_phase4;       // AF_CONV_UP_PHASE4       0 = upsampled 3x3 convolutions gather all nine taps from the upsampled map
   int pp_sched;             // AF_PP_SCHED             eight-wave kernel: 0 = round-1 compute phase (two K halves, a full LDS drain
                             //                         after each), 1 = block-ordered compute phase, 2 = merged (no staging phase)
 };
@@ -278,6 +279,15 @@ struct ConvGemmParams {
   int fp8;
   const unsigned char* w_scale;
   int x_scale_e8;
+  // Nearest-2x upsample + 3x3 convolution as FOUR 2x2 convolutions on the stored (low-resolution) map, one per output
+  // phase (dy, dx) = (Y & 1, X & 1): the three upsampled rows a 3x3 window covers are only two stored rows, so the taps that
+  // read the same stored pixel are summed ONCE at load time (af_launch_up_phase4_weights) and the GEMM does 4/9 of the work.
+  //   caller: W_up4 = phase weights [4][Wrows][4 * Cin] (K = (ty, tx, c)) next to the ordinary 3x3 weights; the launcher
+  //   switches when the shape qualifies (bf16, up = 1, ks = 3, stride 1, power-of-two maps, no residual / time bias)
+  //   kernel (set by the launcher): phase4 = 1 -> blockIdx.y = phase, padding (1 - dy, 1 - dx), rows m = (b, y, x) of the
+  //   STORED map, output pixel (2 y + dy, 2 x + dx) of the [B][2 Hs][2 Ws] map
+  const void* W_up4;
+  int phase4;
 };
 
 struct AfGemmPlan {

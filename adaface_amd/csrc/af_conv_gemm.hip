@@ -586,7 +586,14 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
         const int row = c / cpr, ch = c - row * cpr;
         const int m = m0 + wq * 64 + row;
         const uint4 v = *reinterpret_cast<const uint4*>(wtile + row * wpitch + ch * 16);
-        if (m < p.M) *reinterpret_cast<uint4*>(out + (long)m * p.ldo + ncol0 + g * HNo + ch * 8) = v;
+        long orow = m;
+        if (p.phase4) {   // row m = pixel (b, y, x) of the stored map -> pixel (2 y + dy, 2 x + dx) of the upsampled output
+          const int ph = blockIdx.y;
+          const int b = m >> p.howo_shift, rem = m & ((1 << p.howo_shift) - 1);
+          const int y = rem >> p.wo_shift, x = rem & ((1 << p.wo_shift) - 1);
+          orow = ((long)b << (p.howo_shift + 2)) + ((long)(2 * y + (ph >> 1)) << (p.wo_shift + 1)) + 2 * x + (ph & 1);
+        }
+        if (m < p.M) *reinterpret_cast<uint4*>(out + orow * p.ldo + ncol0 + g * HNo + ch * 8) = v;
       }
     };
 #pragma unroll
@@ -791,6 +798,9 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
   tile_coords(blockIdx.x, gridDim.x, ntm, ntn, p.group_m, tm, tn);
   const int m0 = tm * 256, n0 = tn * BN;
   const int zk = blockIdx.z;
+  // phase-decomposed upsampled convolution (ConvGemmParams::W_up4): blockIdx.y = output phase, its own padding and weights
+  const int ph4 = (GATHER && p.phase4) ? (int)blockIdx.y : 0;
+  const int pad_y = (GATHER && p.phase4) ? 1 - (ph4 >> 1) : p.pad, pad_x = (GATHER && p.phase4) ? 1 - (ph4 & 1) : p.pad;
 
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<T*>(reinterpret_cast<const T*>(p.src)), 0, (int)0xFFFFFFF0u, 0x00020000);
@@ -836,7 +846,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
     }
     unsigned off = (unsigned)((long)b * p.src_batch_stride * XE) + lchunk;
     if constexpr (GATHER) {
-      const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;
+      const int y0 = oy * p.stride - pad_y, x0 = ox * p.stride - pad_x;
       if (fast_taps) {
         // no upsample: the address of tap (ky, kx) is the tap-(0,0) address plus a wave-uniform delta, and whether the tap
         // falls inside the image is one bit of a mask made here (row bits x column bits) -- the staging phase then spends
@@ -863,7 +873,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
 #pragma unroll
   for (int q = 0; q < NWM; ++q) {
     const int n = n0 + ((g == 0 ? 0 : WP0) + wq + 4 * q) * 8 + srow;
-    w_off[q] = n < p.Wrows ? (unsigned)((long)n * p.ldw * XE) + dchunk * 16u : 0xFFFFFFFFu;
+    w_off[q] = n < p.Wrows ? (unsigned)(((long)ph4 * p.Wrows + n) * p.ldw * XE) + dchunk * 16u : 0xFFFFFFFFu;
   }
   // K order.  The sum over (tap, channel chunk) can be walked either way; with the TAP innermost (k_tap_inner) the nine
   // taps of a channel chunk re-read the same few input rows back to back, so eight of nine gathers hit the XCD's L2
@@ -2256,7 +2266,7 @@ AfGemmPlan g_af_last_plan = {0, 1, 0, 0, 1};
 // [7] launches that sliced K (counted in their tile's slot as well), [8] / [9] ping-pong launches with the LayerNorm
 // consumer / statistics-producer epilogue, [10] ping-pong launches with fp8 operands, [11] eight-wave halo launches
 // (counted under tile 5 as well), [12] row-panel GEGLU launches (counted under their planned tile as well)
-long g_af_plan_counts[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+long g_af_plan_counts[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [13]: phase-decomposed upsampled convolutions
 
 
 // tile: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64
@@ -2564,6 +2574,92 @@ template <typename T, int TW, int BN> static int launch_halo(const ConvGemmParam
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Nearest-2x upsample + 3x3 convolution in four phases (ConvGemmParams::W_up4; openaimodel.py:107-113 Upsample.forward,
+// model.py:43-48 for the VAE): F.interpolate(nearest, 2x) followed by a 3x3 / pad-1 convolution reads, for output pixel
+// (2 y + dy, 2 x + dx), the stored rows {y - 1, y} (dy = 0) or {y, y + 1} (dy = 1) -- two of the three window rows are the
+// same stored row -- and likewise for columns.  Summing the weights of the taps that coincide gives an exact (up to the one
+// bf16 rounding of the summed weight) 2x2 convolution per phase on the STORED map: 4 taps instead of 9, and a gather
+// without the >> 1 address arithmetic, so the merged schedule with tap masks applies.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void up_phase4_weights_kernel(const bf16* __restrict__ w3, bf16* __restrict__ w4, long total,
+                                                                int rows, int cin, int ldw3) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int n = (int)(idx / cin), c = (int)(idx - (long)n * cin);
+  float w[3][3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) w[ky][kx] = to_f32<bf16>(w3[(long)n * ldw3 + (ky * 3 + kx) * cin + c]);
+  const long ld4 = 4L * cin;
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph) {
+    const int dy = ph >> 1, dx = ph & 1;
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 2; ++tx) {
+        // window rows of tap ty: dy = 0: {0} | {1, 2};  dy = 1: {0, 1} | {2}
+        const int ylo = ty == 0 ? 0 : (dy == 0 ? 1 : 2), yhi = ty == 0 ? (dy == 0 ? 0 : 1) : 2;
+        const int xlo = tx == 0 ? 0 : (dx == 0 ? 1 : 2), xhi = tx == 0 ? (dx == 0 ? 0 : 1) : 2;
+        float sum = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            if (ky >= ylo && ky <= yhi && kx >= xlo && kx <= xhi) sum += w[ky][kx];
+        w4[((long)ph * rows + n) * ld4 + (ty * 2 + tx) * cin + c] = from_f32<bf16>(sum);
+      }
+  }
+}
+// w3: bf16 [rows][ldw3 >= 9 * cin], K = (ky, kx, c);  w4: bf16 [4][rows][4 * cin], K = (ty, tx, c)
+int af_launch_up_phase4_weights(const void* w3, int rows, int cin, int ldw3, void* w4, hipStream_t stream) {
+  const long total = (long)rows * cin;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(up_phase4_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                     reinterpret_cast<const bf16*>(w3), reinterpret_cast<bf16*>(w4), total, rows, cin, ldw3);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+// does the launcher take the four-phase form for this (validated, bf16) upsampled convolution?
+static bool up_phase4_ok(const ConvGemmParams& p, int batch) {
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  return p.W_up4 && g_af_knobs.conv_up_phase4 && g_af_knobs.gemm_pp && batch == 1 && p.up == 1 && p.ks == 3 && p.stride == 1 &&
+         p.pad == 1 && p.Cin % 64 == 0 && p.ldc >= p.Cin && p.K == 9 * p.Cin && (p.N % 160 == 0 || p.N % 128 == 0) &&
+         pow2(p.Hs) && pow2(p.Ws) && p.Ho == 2 * p.Hs && p.Wo == 2 * p.Ws && p.M == (p.M / (p.Ho * p.Wo)) * p.Ho * p.Wo &&
+         p.M / 4 >= 1024 && !p.residual && !p.rowbias && !p.ln_stats && !p.ln_stats_out && p.epilogue != AF_EPI_GEGLU &&
+         (double)4 * p.Wrows * 4 * p.Cin * 2 < 4294967280.0;
+}
+static int launch_up_phase4(ConvGemmParams p, hipStream_t stream) {
+  auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return s; };
+  const int bn = p.N % 160 == 0 ? 160 : 128;
+  p.W = p.W_up4;
+  p.ks = 2; p.up = 0; p.pad = 1;               // (the kernel takes the padding of its phase: 1 - dy, 1 - dx)
+  p.Hi = p.Ho = p.Hs; p.Wi = p.Wo = p.Ws;      // GEMM rows = pixels of the stored map
+  p.M /= 4;
+  p.K = 4 * p.Cin; p.ldw = p.K;
+  p.k_logical = p.K;                           // FLOPs actually spent (4/9 of the nine-tap form)
+  p.phase4 = 1;
+  p.splitk = 1; p.ws = nullptr;
+  p.howo_shift = lg2(p.Ho * p.Wo);
+  p.wo_shift = lg2(p.Wo);
+  p.pp_epilogue = 2;                           // wave-private transposition: the only epilogue that knows the phase's row map
+  p.k_tap_inner = 1;
+  p.fast_taps = 1;
+  p.pp_stagger = g_af_knobs.pp_stagger;
+  AfGemmPlan pl;
+  pl.tile = bn == 160 ? 5 : 4; pl.splitk = 1; pl.ws_bytes = 0; pl.halo_tw = 0; pl.group_m = 1;
+  plan_group_m(pl, p);
+  p.group_m = pl.group_m > 0 ? pl.group_m : 1;
+  g_af_last_plan = pl;
+  g_af_plan_counts[13] += 1;
+  AfProfScope prof(bn == 160 ? AF_K_PP160_GATHER : AF_K_PP128, stream, 2.0 * p.M * (double)p.N * p.K * 4,
+                   ((double)p.M * p.Cin + 4.0 * p.N * p.K + 4.0 * p.M * p.N) * 2);
+  dim3 grid(((p.M + 255) / 256) * (p.N / bn), 4, 1);
+  return bn == 160 ? launch_pp_one<160, 0, true, false, 2>(p, grid, stream) : launch_pp_one<128, 0, true, false, 2>(p, grid, stream);
+}
+
 template <typename T>
 int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t stream, const AfGemmPlan* plan, void* ws) {
   constexpr int BK = 128 / sizeof(T);
@@ -2597,6 +2693,9 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
                        (src_bytes > w_bytes ? src_bytes : w_bytes) / 1e9);
       return -1;
     }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (up_phase4_ok(p, batch)) return launch_up_phase4(p, stream);
   }
   AfGemmPlan pl = plan ? *plan : af_plan_conv_gemm(p, batch, (int)sizeof(T));
   if (pl.splitk > 1 && !ws) pl.splitk = 1;  // no workspace supplied: fall back to one slice

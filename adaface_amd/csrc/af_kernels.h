@@ -72,7 +72,8 @@ int af_launch_ln_finalize(const float* part, int parts, int M, int count, float 
 
 // plan of the most recent af_launch_conv_gemm (diagnostics, af_last_gemm_plan)
 extern AfGemmPlan g_af_last_plan;
-extern long g_af_plan_counts[13];
+extern long g_af_plan_counts[14];
+int af_launch_up_phase4_weights(const void* w3, int rows, int cin, int ldw3, void* w4, hipStream_t stream);
 // fp8 (e4m3) twin of a repacked bf16 weight (K in 64-channel units, power-of-two row scales) / saturating bf16 -> e4m3 cast
 int af_launch_quant_weight_fp8(const void* w, int rows, int ldw, int cin_pad, int ks, void* w8, int k8, unsigned char* sc,
                                hipStream_t stream);

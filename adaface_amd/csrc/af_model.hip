@@ -53,7 +53,7 @@ AfKnobs g_af_knobs = {
     knob_env("AF_PP_DIRECT", -1),      knob_env("AF_ATTN_W4", 1),         knob_env("AF_ATTN_RING", 1),
     knob_env("AF_GN_SMALL", 1),        knob_env("AF_GN_FOLD", 1),         knob_env("AF_CONV_TAP_INNER", 1),
     knob_env("AF_LN_FUSE", 1),         knob_env("AF_GEGLU_ROWPANEL", 3), knob_env("AF_CONV_HALO8", 1), knob_env("AF_CONV_FAST_TAPS", 1),
-    knob_env("AF_PP_STAGGER", 1),
+    knob_env("AF_PP_STAGGER", 1),      knob_env("AF_CONV_UP_PHASE4", 1),
     knob_env("AF_PP_SCHED", 2)};
 static const AfKnobs g_af_knobs_initial = g_af_knobs;
 static int* knob_slot(const char* name) {
@@ -63,7 +63,7 @@ static int* knob_slot(const char* name) {
       {"gemm_tile", &AfKnobs::gemm_tile}, {"gemm_splitk", &AfKnobs::gemm_splitk}, {"gemm_groupm", &AfKnobs::gemm_groupm},
       {"gemm_dma", &AfKnobs::gemm_dma}, {"pp_direct", &AfKnobs::pp_direct}, {"attn_w4", &AfKnobs::attn_w4}, {"attn_ring", &AfKnobs::attn_ring},
       {"gn_small", &AfKnobs::gn_small}, {"gn_fold", &AfKnobs::gn_fold}, {"conv_tap_inner", &AfKnobs::conv_tap_inner}, {"ln_fuse", &AfKnobs::ln_fuse},
-      {"geglu_rowpanel", &AfKnobs::geglu_rowpanel}, {"conv_halo8", &AfKnobs::conv_halo8}, {"conv_fast_taps", &AfKnobs::conv_fast_taps}, {"pp_stagger", &AfKnobs::pp_stagger}, {"pp_sched", &AfKnobs::pp_sched}};
+      {"geglu_rowpanel", &AfKnobs::geglu_rowpanel}, {"conv_halo8", &AfKnobs::conv_halo8}, {"conv_fast_taps", &AfKnobs::conv_fast_taps}, {"pp_stagger", &AfKnobs::pp_stagger}, {"conv_up_phase4", &AfKnobs::conv_up_phase4}, {"pp_sched", &AfKnobs::pp_sched}};
   if (!name) return nullptr;
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) return &(g_af_knobs.*(t.m));
@@ -158,6 +158,8 @@ struct Linear {  // conv or linear weight, repacked [rows_pad][ldw] in storage d
   void* w8 = nullptr;
   unsigned char* sc8 = nullptr;
   int k8 = 0;
+  // phase weights of an upsampled 3x3 convolution (ConvGemmParams::W_up4): bf16 [4][rows_pad][4 * cin_pad]
+  void* w_up4 = nullptr;
 };
 // fp8 activations hold value * 2^3: SiLU(GroupNorm) outputs saturate at +-56 and keep e4m3's 3-bit mantissa down to 2^-9
 constexpr int AF_FP8_ACT_SHIFT = 3;
@@ -277,6 +279,7 @@ struct af_handle {
   bool ln_fold_dirty = true;   // folded LayerNorm twins must be recomputed (a UNet tensor was loaded since)
   bool fp8_on = false;         // af_set_fp8: ResBlock 3x3 convolutions of the UNet on the block-scaled fp8 MFMA
   bool fp8_dirty = true;       // fp8 weight twins must be (re)quantised
+  bool up4_dirty = true;       // phase weights of the upsampled convolutions must be (re)summed
 
   // diagnostic tap (af_unet_set_tap): block whose output the next forwards also write, fp32 NCHW
   int tap_index = -1;
@@ -796,6 +799,7 @@ struct Runner {
     p.out = out.p; p.ldo = out.ld;
     p.epilogue = L.geglu ? AF_EPI_GEGLU : AF_EPI_NONE;
     p.alpha = 1.0f;
+    p.W_up4 = up ? L.w_up4 : nullptr;
     if (x.f8) {   // fp8 operands: the twin's K layout and scales (strides of an e4m3 tensor are bytes = elements)
       p.fp8 = 1;
       p.W = L.w8; p.ldw = L.k8; p.K = L.k8;
@@ -1119,6 +1123,32 @@ static int ensure_fp8_twins(af_handle* h, hipStream_t s) {
     }
   }
   h->fp8_dirty = false;
+  return 0;
+}
+
+// phase weights of the Upsample convolutions (UNet output blocks, VAE decoder): allocated on first use, re-summed after loads
+static int ensure_up4_twins(af_handle* h, hipStream_t s) {
+  if (!h->up4_dirty) return 0;
+  h->up4_dirty = false;
+  if (h->dtype != AF_DTYPE_BF16) return 0;
+  std::vector<Linear*> ups;
+  for (auto& ub : h->output_blocks)
+    for (auto& l : ub.layers)
+      if (l.kind == L_UP) ups.push_back(&h->updown[l.idx]);
+  for (auto& u : h->vup) ups.push_back(&u);
+  for (Linear* L : ups) {
+    if (L->ks != 3 || L->cin_pad % 64 != 0) continue;
+    if (!L->w_up4) {
+      void* p = nullptr;
+      if (hipMalloc(&p, (size_t)4 * L->rows_pad * 4 * L->cin_pad * 2) != hipSuccess) {
+        af_set_error_msg("hipMalloc of the phase weights of an upsampled convolution failed");
+        return AF_ERR_HIP;
+      }
+      h->owned.push_back(p);
+      L->w_up4 = p;
+    }
+    AF_TRY(af_launch_up_phase4_weights(L->w, L->rows_pad, L->cin_pad, L->ldw, L->w_up4, s));
+  }
   return 0;
 }
 
@@ -1644,6 +1674,7 @@ static int load_tensor_impl(af_handle* h, const char* name, const float* host_da
   s.loaded = true;
   h->ln_fold_dirty = true;
   h->fp8_dirty = true;
+  h->up4_dirty = true;
   return 0;
 }
 
@@ -1776,6 +1807,7 @@ int af_unet_forward(af_handle* h, const float* x_dev, const int64_t* t_dev, floa
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   AF_TRY(fold_layernorms(h, s));
   AF_TRY(ensure_fp8_twins(h, s));
+  AF_TRY(ensure_up4_twins(h, s));
   // size the arena with a dry run
   h->arena.dry = true; h->arena.peak = 0;
   int rc = unet_forward_impl(h, s, x_dev, t_dev, eps_dev, Bf, H, W);
@@ -1889,6 +1921,7 @@ int af_vae_decode(af_handle* h, const float* z_dev, float scale_factor, float* i
   AF_TRY(check_loaded(h, "first_stage_model.decoder."));
   AF_TRY(check_loaded(h, "first_stage_model.post_quant_conv."));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  AF_TRY(ensure_up4_twins(h, s));
   h->arena.dry = true; h->arena.peak = 0;
   int rc = vae_decode_impl(h, s, z_dev, scale_factor, img_dev, u8_dev, B, H, W);
   h->arena.dry = false;
@@ -1971,12 +2004,13 @@ int af_gemm_plan_counts(int64_t* counts10) {
   return AF_OK;
 }
 int af_gemm_plan_counts_reset(void) {
-  for (int i = 0; i < 13; ++i) g_af_plan_counts[i] = 0;
+  for (int i = 0; i < 14; ++i) g_af_plan_counts[i] = 0;
   return AF_OK;
 }
 int64_t af_fp8_gemm_launches(void) { return g_af_plan_counts[10]; }
 int64_t af_halo8_launches(void) { return g_af_plan_counts[11]; }
 int64_t af_rowpanel_launches(void) { return g_af_plan_counts[12]; }
+int64_t af_up_phase4_launches(void) { return g_af_plan_counts[13]; }
 int af_set_fp8(af_handle* h, int on) {
   if (!h) { af_set_error_msg("af_set_fp8: null handle"); return AF_ERR_INVALID; }
   if (on && h->dtype != AF_DTYPE_BF16) { af_set_error_msg("af_set_fp8: the fp8 convolutions extend the bf16 mode (handle is f32)"); return AF_ERR_STATE; }

@@ -80,6 +80,12 @@ int af_op_conv2d(int dtype, const float* x_dev, const float* w_dev, const float*
   p.M = B * Ho * Wo; p.N = co4; p.K = ldw;
   p.bias = bn; p.residual = rn; p.ldr = co4; p.out = yn; p.ldo = co4; p.alpha = 1.f;
   p.k_logical = ks * ks * Cin;
+  if (upsample && ks == 3 && dtype == AF_DTYPE_BF16 && cin_pad % 64 == 0) {
+    // as the model does for its Upsample layers: phase weights next to the 3x3 ones, the launcher decides (AF_CONV_UP_PHASE4)
+    OP_ALLOC(w4, (size_t)4 * rows_pad * 4 * cin_pad * 2, false);
+    OP_TRY(af_launch_up_phase4_weights(wn, rows_pad, cin_pad, ldw, w4, s));
+    p.W_up4 = w4;
+  }
   const AfGemmPlan pl = af_plan_conv_gemm(p, 1, (int)esz(dtype));
   void* ws = nullptr;
   if (pl.splitk > 1) { ws = tmp.get(pl.ws_bytes, false); if (!ws) return AF_ERR_HIP; }

@@ -215,6 +215,7 @@ int af_op_groupnorm(int dtype, const float* x_dev, const float* gamma_dev, const
 int af_set_fp8(af_handle* h, int on);
 int64_t af_fp8_gemm_launches(void); /* launches on the fp8 kernel since af_gemm_plan_counts_reset */
 int64_t af_halo8_launches(void);    /* launches of the eight-wave LDS-halo 3x3 kernel (also counted under tile 5) */
+int64_t af_up_phase4_launches(void); /* upsampled 3x3 convolutions run as four 2x2 phase convolutions on the stored map */
 int64_t af_rowpanel_launches(void); /* launches of the row-panel GEGLU kernel (K = 320, activations resident in registers) */
 int af_op_conv2d_fp8(const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev, float* y_dev,
                      int B, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int upsample, int act_shift,

@@ -7,6 +7,8 @@ Tolerances are relative to max|reference| and are stated here, not tuned per cas
 """
 import math
 
+import numpy as np
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -172,6 +174,38 @@ def test_conv2d_pingpong(gpu, report, knobs, B, Cin, H, W, Cout, ks, stride, up,
     tile, sk, halo = _last_plan()
     assert tile in (4, 5) and halo == 0 and (splitk == 1 or sk == splitk), (tile, sk, halo)  # planner may slice K itself
     _cmp(report, f"pp conv{ks}x{ks} {Cin}->{Cout}@{H}x{W} s{stride} up{int(up)} sk{splitk}", got, ref, dtype)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,bias", [
+    (4, 128, 16, 16, 320, True),      # 1024 stored pixels per phase: the smallest the launcher takes; two N tiles of 160
+    (2, 64, 32, 64, 128, False),      # non-square power-of-two map, the 256 x 128 tile (VAE widths), one channel chunk
+    (16, 640, 32, 32, 640, True),     # UNet output block 8: [16, 640, 32, 32] -> 64 x 64
+    (1, 192, 32, 32, 160, True),      # three channel chunks, one sample
+])
+def test_conv2d_up_phase4(gpu, report, knobs, B, Cin, H, W, Cout, bias):
+    """Upsample (nearest 2x) + 3x3 convolution as four 2x2 phase convolutions on the stored map (ConvGemmParams::W_up4):
+    against torch's interpolate + conv2d on the same bf16 operands, and against the nine-tap gathering kernel -- the two differ
+    only by the bf16 rounding of the pre-summed weights (and the summation order)."""
+    from adaface_amd import _lib, ops
+    dtype = "bf16"
+    g = torch.Generator().manual_seed(B + Cin + Cout + H)
+    x = _q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = _q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9), dtype)
+    b = torch.randn(Cout, generator=g) * 0.1 if bias else None
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    args = (x.to(gpu), w.to(gpu), None if b is None else b.to(gpu))
+    _lib.plan_counts(reset=True)
+    got = ops.conv2d(*args, upsample=True, dtype=dtype)
+    assert _lib.plan_counts(reset=True)["up_phase4"] == 1
+    _cmp(report, f"up-phase4 conv3x3 {Cin}->{Cout}@{H}x{W}->{2 * H}x{2 * W}", got, ref, dtype)
+    knobs("conv_up_phase4", 0)
+    nine = ops.conv2d(*args, upsample=True, dtype=dtype)
+    assert _lib.plan_counts(reset=True)["up_phase4"] == 0
+    scale = ref.abs().max().item()
+    assert (got.cpu() - nine.cpu()).abs().max().item() <= 2e-2 * scale
+    # borders: the first / last output rows and columns see the zero padding through different phases
+    for sl in (np.s_[..., 0, :], np.s_[..., -1, :], np.s_[..., :, 0], np.s_[..., :, -1]):
+        assert torch.allclose(got.cpu()[sl], ref[sl], atol=2e-2 * scale, rtol=0)
 
 
 @pytest.mark.parametrize("M,K,N,bias", [(32768, 320, 1280, True), (32868, 320, 640, False), (65536, 320, 1280, True),
