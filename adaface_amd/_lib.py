@@ -60,6 +60,7 @@ _SIGS = [
     ("af_tensor_shape", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
     ("af_set_context", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("af_unet_forward", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    ("af_unet_forward_twin", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("af_ddim_step", C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, _P, _P, _P]),
     ("af_lincomb", C.c_int, [_P, C.c_int64, _P, C.c_float, _P, C.c_float, _P, C.c_float, _P, C.c_float, C.c_int, _P]),

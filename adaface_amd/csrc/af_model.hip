@@ -927,12 +927,26 @@ static int run_resblock(Runner& R, const ResBlockW& w, const Act& x, Act& out, c
 }
 
 // SpatialTransformer.forward (attention.py:321-341) incl. BasicTransformerBlock (:275-285)
-static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out) {
+// twin (classifier-free-guidance batch [x; x], af_unet_forward_twin): x holds the FIRST half of the batch (x.B = B / 2, its
+// buffer has room for B samples).  Everything up to the first cross-attention is independent of the context and therefore
+// identical for the two halves: GroupNorm, proj_in, norm1 + q/k/v, the self-attention and to_out of the first block run on
+// the first half only, and their result (and x, for proj_out's residual) is copied onto the second half.
+static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out, bool twin = false) {
   af_handle* h = R.h;
   const size_t mk = R.A.mark();
-  const int B = x.B, H = x.H, W = x.W, N = H * W, C = w.heads * w.dh;
+  const int Bh = x.B, B = twin ? 2 * x.B : x.B, H = x.H, W = x.W, N = H * W, C = w.heads * w.dh;
+  auto half = [&](Act a) { if (twin) a.B = Bh; return a; };   // first-half view: the batch is the outermost dimension
+  auto dup = [&](const Act& a) -> int {                        // samples 0 .. Bh-1 onto Bh .. 2 Bh-1
+    Act src = a, dst = a;
+    src.B = dst.B = Bh;
+    dst.p = R.elem_ptr(a.p, (long)Bh * a.H * a.W * a.ld);
+    return R.copy_channels(src, dst, 0);
+  };
   Act g = R.alloc_act(B, H, W, x.C);
-  AF_TRY(R.groupnorm(w.gn, x, g, 0));
+  {
+    Act gh = half(g);
+    AF_TRY(R.groupnorm(w.gn, x, gh, 0));
+  }
   Act t = R.alloc_act(B, H, W, C);
   // LayerNorm folding (bf16): when every GEMM around the three LayerNorms of a block runs on the ping-pong kernel in
   // one K slice, the producer of each normalised tensor also writes per-row partial sums and the consumer GEMM applies
@@ -949,6 +963,11 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out) {
                     R.ln_capable(b0.ff2, f_probe, t) == pp && R.ln_capable(b0.qkv1_ln, t, qkv_probe) > 0 &&
                     R.ln_capable(b0.q2_ln, t, t) > 0 && R.ln_capable(b0.ff1_ln, t, f_probe, 8 * C) > 0;
     if (ok) ln_parts = pp;
+    if (ok && twin) {   // the half-batch launches of the prefix must fold as well
+      const Act gh = half(g), th = half(t), qh = half(qkv_probe);
+      if (R.ln_capable(w.proj_in, gh, th) != pp || R.ln_capable(b0.out1, th, th) != pp || R.ln_capable(b0.qkv1_ln, th, qh) <= 0)
+        ln_parts = 0;
+    }
   }
   const size_t st_elems = (size_t)ln_parts * B * N * 2;
   float* st_part = ln_parts ? reinterpret_cast<float*>(R.A.alloc(st_elems * sizeof(float))) : nullptr;       // partial sums
@@ -962,43 +981,65 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out) {
     (void)st; (void)ln;
     return a;
   };
-  auto finalize = [&](const float* st, const Norm& ln) { return R.ln_finalize(st, ln_parts, (long)B * N, C, ln.eps, st_row); };
+  // (rows: the statistics of a half-batch producer are laid out for ITS row count)
+  auto finalize = [&](const float* st, const Norm& ln, long rows) { return R.ln_finalize(st, ln_parts, rows, C, ln.eps, st_row); };
   {
     const Runner::LnArgs pa = producer(st_t);
-    AF_TRY(R.conv(w.proj_in, g, t, 1, 0, nullptr, nullptr, 0, -1, -1, ln_parts ? &pa : nullptr));
+    const Act gh = half(g);
+    Act th = half(t);
+    AF_TRY(R.conv(w.proj_in, gh, th, 1, 0, nullptr, nullptr, 0, -1, -1, ln_parts ? &pa : nullptr));
   }
   for (size_t d = 0; d < w.blocks.size(); ++d) {
     const XfmrBlockW& blk = w.blocks[d];
     const size_t mk2 = R.A.mark();
+    const bool pre = twin && d == 0;             // this block's self-attention runs on the first half only
+    const int Bp = pre ? Bh : B;
+    auto pv = [&](Act a) { a.B = Bp; return a; };
     // --- x = attn1(norm1(x)) + x ---
     Act n = R.alloc_act(B, H, W, C);
     Act qkv = R.alloc_act(B, H, W, 3 * C);
-    if (R.fp8_capable(blk.qkv1, t, qkv)) {
-      // fp8 mode: LayerNorm writes e4m3 and the q / k / v projection multiplies on the block-scaled fp8 MFMA (the
-      // un-folded weights: its producer's row statistics, if any, simply go unused)
-      Act n8 = R.alloc_act8(B, H, W, C);
-      AF_TRY(R.layernorm(blk.ln1, t, n8));
-      AF_TRY(R.conv(blk.qkv1, n8, qkv, 1, 0, nullptr, nullptr, 0));
-    } else if (ln_parts) {
-      AF_TRY(finalize(st_t, blk.ln1));
-      const Runner::LnArgs ca = consumer(st_t, blk.qkv1_cs, blk.ln1);
-      AF_TRY(R.conv(blk.qkv1_ln, t, qkv, 1, 0, nullptr, nullptr, 0, -1, -1, &ca));
-    } else {
-      AF_TRY(R.layernorm(blk.ln1, t, n));
-      AF_TRY(R.conv(blk.qkv1, n, qkv, 1, 0, nullptr, nullptr, 0));
+    {
+      const Act tp = pv(t);
+      Act np = pv(n), qkvp = pv(qkv);
+      if (R.fp8_capable(blk.qkv1, tp, qkvp)) {
+        // fp8 mode: LayerNorm writes e4m3 and the q / k / v projection multiplies on the block-scaled fp8 MFMA (the
+        // un-folded weights: its producer's row statistics, if any, simply go unused)
+        Act n8 = R.alloc_act8(Bp, H, W, C);
+        AF_TRY(R.layernorm(blk.ln1, tp, n8));
+        AF_TRY(R.conv(blk.qkv1, n8, qkvp, 1, 0, nullptr, nullptr, 0));
+      } else if (ln_parts) {
+        AF_TRY(finalize(st_t, blk.ln1, (long)Bp * N));
+        const Runner::LnArgs ca = consumer(st_t, blk.qkv1_cs, blk.ln1);
+        AF_TRY(R.conv(blk.qkv1_ln, tp, qkvp, 1, 0, nullptr, nullptr, 0, -1, -1, &ca));
+      } else {
+        AF_TRY(R.layernorm(blk.ln1, tp, np));
+        AF_TRY(R.conv(blk.qkv1, np, qkvp, 1, 0, nullptr, nullptr, 0));
+      }
     }
     Act a = R.alloc_act(B, H, W, C);
-    AF_TRY(R.attention(qkv.p, 3 * C, (long)N * 3 * C, R.elem_ptr(qkv.p, C), 3 * C, (long)N * 3 * C,
-                       R.elem_ptr(qkv.p, 2 * C), 3 * C, (long)N * 3 * C, a, N, N, w.heads, w.dh));
+    {
+      Act ap = pv(a);
+      AF_TRY(R.attention(qkv.p, 3 * C, (long)N * 3 * C, R.elem_ptr(qkv.p, C), 3 * C, (long)N * 3 * C,
+                         R.elem_ptr(qkv.p, 2 * C), 3 * C, (long)N * 3 * C, ap, N, N, w.heads, w.dh));
+    }
     Act t1 = R.alloc_act(B, H, W, C);
     {
       const Runner::LnArgs pa = producer(st_1);
-      AF_TRY(R.conv(blk.out1, a, t1, 1, 0, &t, nullptr, 0, -1, -1, ln_parts ? &pa : nullptr));
+      const Act ap = pv(a), tp = pv(t);
+      Act t1p = pv(t1);
+      AF_TRY(R.conv(blk.out1, ap, t1p, 1, 0, &tp, nullptr, 0, -1, -1, ln_parts ? &pa : nullptr));
+    }
+    if (pre) {   // from here on the halves differ (cross-attention): second half := first half
+      AF_TRY(R.check(t1));
+      AF_TRY(dup(t1));
+      AF_TRY(dup(x));
     }
     // --- x = x + attn2(norm2(x), context) ---
     Act q = R.alloc_act(B, H, W, C);
     if (ln_parts) {
-      AF_TRY(finalize(st_1, blk.ln2));
+      AF_TRY(finalize(st_1, blk.ln2, (long)Bp * N));
+      if (pre && !R.dry)   // (mu, rstd) of the first half's rows serve the second half as well
+        HIP_CHECK_RET(hipMemcpyAsync(st_row + (size_t)Bh * N * 2, st_row, (size_t)Bh * N * 2 * sizeof(float), hipMemcpyDeviceToDevice, R.s));
       const Runner::LnArgs ca = consumer(st_1, blk.q2_cs, blk.ln2);
       AF_TRY(R.conv(blk.q2_ln, t1, q, 1, 0, nullptr, nullptr, 0, -1, -1, &ca));
     } else {
@@ -1059,7 +1100,7 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out) {
     // --- x = ff(norm3(x)) + x ---
     Act f = R.alloc_act(B, H, W, 4 * C);
     if (ln_parts) {
-      AF_TRY(finalize(st_2, blk.ln3));
+      AF_TRY(finalize(st_2, blk.ln3, (long)B * N));
       const Runner::LnArgs ca = consumer(st_2, blk.ff1_cs, blk.ln3);
       AF_TRY(R.conv(blk.ff1_ln, t2, f, 1, 0, nullptr, nullptr, 0, 8 * C, -1, &ca));
     } else {
@@ -1073,7 +1114,11 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out) {
     }
     R.A.release(mk2);
   }
-  AF_TRY(R.conv(w.proj_out, t, out, 1, 0, &x, nullptr, 0));
+  {
+    Act xf = x;
+    xf.B = B;
+    AF_TRY(R.conv(w.proj_out, t, out, 1, 0, &xf, nullptr, 0));
+  }
   R.A.release(mk);
   return 0;
 }
@@ -1169,13 +1214,27 @@ static int ensure_arena(af_handle* h, size_t need) {
 }
 
 // UNetModel.forward (openaimodel.py:827-1052)
+// twin: x_dev / t_dev hold Bf / 2 samples and the batch is [x; x], [t; t] -- classifier-free guidance as p_sample_ddim
+// builds it (ddim.py:236-247: torch.cat([x] * 2), cond first).  The time embedding, conv_in, the first ResBlock and the
+// first transformer up to its cross-attention do not see the context: they run on Bf / 2 samples and are copied.
 static int unet_forward_impl(af_handle* h, hipStream_t s, const float* x_dev, const int64_t* t_dev, float* eps_dev,
-                             int Bf, int H, int W) {
+                             int Bf, int H, int W, bool twin = false) {
   Runner R(h, s);
   const af_config& c = h->cfg;
   const int dt = h->dtype;
   const int mc = c.model_channels, ted = 4 * mc;
   R.A.off = 0;
+  const int Bin = twin ? Bf / 2 : Bf;          // samples behind x_dev / t_dev
+  auto dup_half = [&](const Act& a) -> int {    // samples 0 .. Bin-1 of a full-batch buffer onto Bin .. Bf-1
+    Act src = a, dst = a;
+    src.B = dst.B = Bin;
+    dst.p = R.elem_ptr(a.p, (long)Bin * a.H * a.W * a.ld);
+    return R.copy_channels(src, dst, 0);
+  };
+  // the prefix shortcut needs SD's block structure: input_blocks[0] = conv_in, input_blocks[1] = ResBlock + transformer
+  const bool twin_prefix = twin && h->input_blocks.size() >= 2 && h->input_blocks[0].layers.size() == 1 &&
+                           h->input_blocks[0].layers[0].kind == L_CONV_IN && h->input_blocks[1].layers.size() == 2 &&
+                           h->input_blocks[1].layers[0].kind == L_RES && h->input_blocks[1].layers[1].kind == L_XFMR;
 
   // x -> NHWC with channels zero-padded to the first conv's K tile
   Act x = R.alloc_act(Bf, H, W, c.in_channels, h->conv_in.cin_pad);
@@ -1188,30 +1247,43 @@ static int unet_forward_impl(af_handle* h, hipStream_t s, const float* x_dev, co
   Act emb_all = R.alloc_act(Bf, 1, 1, h->emb_total);
   AF_TRY(R.check(emb_all));
   if (!R.dry) {
-    AF_TRY(DISPATCH(dt, af_launch_nchw_to_nhwc<bf16>(x_dev, x.p, Bf, c.in_channels, H * W, x.ld, 1.0f, s),
-                    af_launch_nchw_to_nhwc<float>(x_dev, x.p, Bf, c.in_channels, H * W, x.ld, 1.0f, s)));
-    AF_TRY(DISPATCH(dt, af_launch_timestep_embedding<bf16>((const long long*)t_dev, temb.p, Bf, mc, s),
-                    af_launch_timestep_embedding<float>((const long long*)t_dev, temb.p, Bf, mc, s)));
+    AF_TRY(DISPATCH(dt, af_launch_nchw_to_nhwc<bf16>(x_dev, x.p, Bin, c.in_channels, H * W, x.ld, 1.0f, s),
+                    af_launch_nchw_to_nhwc<float>(x_dev, x.p, Bin, c.in_channels, H * W, x.ld, 1.0f, s)));
+    AF_TRY(DISPATCH(dt, af_launch_timestep_embedding<bf16>((const long long*)t_dev, temb.p, Bin, mc, s),
+                    af_launch_timestep_embedding<float>((const long long*)t_dev, temb.p, Bin, mc, s)));
   }
-  AF_TRY(R.conv(h->time_embed0, temb, e1, 1, 0, nullptr, nullptr, 0));
-  if (!R.dry) AF_TRY(DISPATCH(dt, af_launch_silu<bf16>(e1.p, e1.p, (long)Bf * ted, s), af_launch_silu<float>(e1.p, e1.p, (long)Bf * ted, s)));
-  AF_TRY(R.conv(h->time_embed2, e1, e2, 1, 0, nullptr, nullptr, 0));
-  if (!R.dry) AF_TRY(DISPATCH(dt, af_launch_silu<bf16>(e2.p, e2.p, (long)Bf * ted, s), af_launch_silu<float>(e2.p, e2.p, (long)Bf * ted, s)));
-  AF_TRY(R.conv(h->emb_all, e2, emb_all, 1, 0, nullptr, nullptr, 0));
+  if (twin && !twin_prefix) AF_TRY(dup_half(x));   // other block structures: the whole network on [x; x]
+  {
+    // (twin: the embeddings of the Bin distinct timesteps, then copied)
+    Act tb = temb, e1b = e1, e2b = e2, eab = emb_all;
+    tb.B = e1b.B = e2b.B = eab.B = Bin;
+    AF_TRY(R.conv(h->time_embed0, tb, e1b, 1, 0, nullptr, nullptr, 0));
+    if (!R.dry) AF_TRY(DISPATCH(dt, af_launch_silu<bf16>(e1.p, e1.p, (long)Bin * ted, s), af_launch_silu<float>(e1.p, e1.p, (long)Bin * ted, s)));
+    AF_TRY(R.conv(h->time_embed2, e1b, e2b, 1, 0, nullptr, nullptr, 0));
+    if (!R.dry) AF_TRY(DISPATCH(dt, af_launch_silu<bf16>(e2.p, e2.p, (long)Bin * ted, s), af_launch_silu<float>(e2.p, e2.p, (long)Bin * ted, s)));
+    AF_TRY(R.conv(h->emb_all, e2b, eab, 1, 0, nullptr, nullptr, 0));
+    if (twin) AF_TRY(dup_half(emb_all));
+  }
 
   // `final_out` (optional): a pre-assigned view for the block's last layer (zero-copy skip concat, see below)
-  auto run_block = [&](const UBlock& ub, Act hcur, Act& result, const Act* final_out) -> int {
+  // nb: samples the block computes (the buffers always have room for Bf); twin_x: the block's transformer gets the first
+  // half of the batch only and runs its context-independent prefix on it (run_xfmr)
+  auto run_block = [&](const UBlock& ub, Act hcur, Act& result, const Act* final_out, int nb, bool twin_x) -> int {
+    hcur.B = nb;
     for (size_t li = 0; li < ub.layers.size(); ++li) {
       const LayerRef& l = ub.layers[li];
       const bool use_final = final_out && li + 1 == ub.layers.size();
       Act out;
       auto new_act = [&](int Hh, int Ww, int Cc) -> Act {
+        Act v;
         if (use_final) {
-          Act v = *final_out;
+          v = *final_out;
           if (v.H != Hh || v.W != Ww || v.C != Cc) v.p = nullptr;  // plan mismatch -> reported by check()
-          return v;
+        } else {
+          v = R.alloc_act(Bf, Hh, Ww, Cc);
         }
-        return R.alloc_act(Bf, Hh, Ww, Cc);
+        v.B = nb;
+        return v;
       };
       switch (l.kind) {
         case L_CONV_IN: {
@@ -1227,7 +1299,13 @@ static int unet_forward_impl(af_handle* h, hipStream_t s, const float* x_dev, co
         } break;
         case L_XFMR: {
           out = new_act(hcur.H, hcur.W, hcur.C);
-          AF_TRY(run_xfmr(R, h->xf[l.idx], hcur, out));
+          if (twin_x) {
+            out.B = 2 * nb;
+            nb = 2 * nb;     // (the transformer's output is the whole batch again)
+            AF_TRY(run_xfmr(R, h->xf[l.idx], hcur, out, true));
+          } else {
+            AF_TRY(run_xfmr(R, h->xf[l.idx], hcur, out));
+          }
         } break;
         case L_DOWN: {
           out = new_act(hcur.H / 2, hcur.W / 2, hcur.C);
@@ -1293,11 +1371,19 @@ static int unet_forward_impl(af_handle* h, hipStream_t s, const float* x_dev, co
   for (int i = 0; i < n_in; ++i) {
     const int j = n_in - 1 - i;  // the output block that will consume this skip
     Act o;
+    // twin: block 0 (conv_in) on the first half, copied (it is a skip connection); block 1 = ResBlock on the first half +
+    // the transformer, which returns the whole batch
+    const int nb = (twin_prefix && i < 2) ? Bin : Bf;
+    const bool twin_x = twin_prefix && i == 1;
     if (j < n_out) {
       const Act dst = view(cat[j], ch_h[j], shp_in[i].C);
-      AF_TRY(run_block(h->input_blocks[i], hcur, o, &dst));
+      AF_TRY(run_block(h->input_blocks[i], hcur, o, &dst, nb, twin_x));
     } else {
-      AF_TRY(run_block(h->input_blocks[i], hcur, o, nullptr));
+      AF_TRY(run_block(h->input_blocks[i], hcur, o, nullptr, nb, twin_x));
+    }
+    if (twin_prefix && i == 0) {
+      AF_TRY(dup_half(o));
+      o.B = Bf;
     }
     hcur = o;
     AF_TRY(tap(i, hcur));
@@ -1305,7 +1391,7 @@ static int unet_forward_impl(af_handle* h, hipStream_t s, const float* x_dev, co
   {
     Act o;
     const Act dst = view(cat[0], 0, ch_h[0]);
-    AF_TRY(run_block(h->middle_block, hcur, o, n_out > 0 ? &dst : nullptr));
+    AF_TRY(run_block(h->middle_block, hcur, o, n_out > 0 ? &dst : nullptr, Bf, false));
     hcur = o;
     AF_TRY(tap(n_in, hcur));
   }
@@ -1313,9 +1399,9 @@ static int unet_forward_impl(af_handle* h, hipStream_t s, const float* x_dev, co
     Act o;
     if (j + 1 < n_out) {
       const Act dst = view(cat[j + 1], 0, ch_h[j + 1]);
-      AF_TRY(run_block(h->output_blocks[j], cat[j], o, &dst));
+      AF_TRY(run_block(h->output_blocks[j], cat[j], o, &dst, Bf, false));
     } else {
-      AF_TRY(run_block(h->output_blocks[j], cat[j], o, nullptr));
+      AF_TRY(run_block(h->output_blocks[j], cat[j], o, nullptr, Bf, false));
     }
     hcur = o;
     AF_TRY(tap(n_in + 1 + j, hcur));
@@ -1796,9 +1882,10 @@ int af_set_context(af_handle* h, const float* ctx_dev, int Bf, int n_tokens, int
   return 0;
 }
 
-int af_unet_forward(af_handle* h, const float* x_dev, const int64_t* t_dev, float* eps_dev, int Bf, int H, int W,
-                    void* stream) {
+static int unet_forward_entry(af_handle* h, const float* x_dev, const int64_t* t_dev, float* eps_dev, int Bf, int H, int W,
+                              void* stream, bool twin) {
   if (!h || !x_dev || !t_dev || !eps_dev) { af_set_error_msg("af_unet_forward: null argument"); return AF_ERR_INVALID; }
+  if (twin && (Bf < 2 || Bf % 2)) { af_set_error_msg("af_unet_forward_twin: the batch [x; x] must be even, got %d", Bf); return AF_ERR_INVALID; }
   if (!h->cfg.build_unet) { af_set_error_msg("af_unet_forward: handle has no UNet"); return AF_ERR_STATE; }
   if (!h->ctx_set || h->ctx_Bf != Bf) { af_set_error_msg("af_unet_forward: call af_set_context for batch %d first", Bf); return AF_ERR_STATE; }
   const int down = 1 << (h->cfg.n_channel_mult - 1);
@@ -1810,11 +1897,19 @@ int af_unet_forward(af_handle* h, const float* x_dev, const int64_t* t_dev, floa
   AF_TRY(ensure_up4_twins(h, s));
   // size the arena with a dry run
   h->arena.dry = true; h->arena.peak = 0;
-  int rc = unet_forward_impl(h, s, x_dev, t_dev, eps_dev, Bf, H, W);
+  int rc = unet_forward_impl(h, s, x_dev, t_dev, eps_dev, Bf, H, W, twin);
   h->arena.dry = false;
   if (rc) return rc;
   if (h->arena.peak > h->arena.cap) { HIP_CHECK_RET(hipStreamSynchronize(s)); AF_TRY(ensure_arena(h, h->arena.peak)); }
-  return unet_forward_impl(h, s, x_dev, t_dev, eps_dev, Bf, H, W);
+  return unet_forward_impl(h, s, x_dev, t_dev, eps_dev, Bf, H, W, twin);
+}
+int af_unet_forward(af_handle* h, const float* x_dev, const int64_t* t_dev, float* eps_dev, int Bf, int H, int W,
+                    void* stream) {
+  return unet_forward_entry(h, x_dev, t_dev, eps_dev, Bf, H, W, stream, false);
+}
+int af_unet_forward_twin(af_handle* h, const float* x_dev, const int64_t* t_dev, float* eps_dev, int Bf, int H, int W,
+                         void* stream) {
+  return unet_forward_entry(h, x_dev, t_dev, eps_dev, Bf, H, W, stream, true);
 }
 
 int af_unet_num_blocks(af_handle* h) {

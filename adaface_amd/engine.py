@@ -158,6 +158,18 @@ class Engine:
         check(self._lib.af_unet_forward(self._h, ptr(x), ptr(t), ptr(out), Bf, H, W, stream_ptr()), "af_unet_forward")
         return out
 
+    def unet_forward_twin(self, x: torch.Tensor, t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """af_unet_forward_twin: the UNet on the CFG batch [x; x], [t; t] (context set for 2 * len(x) samples, cond first)
+        without materialising the concatenation; the context-independent prefix runs once.  Returns eps [2B, C, H, W]."""
+        x = x.contiguous().float()
+        t = t.contiguous().long()
+        B, _, H, W = x.shape
+        if out is None:
+            out = torch.empty(2 * B, self.unet_cfg["out_channels"], H, W, device=x.device, dtype=torch.float32)
+        check(self._lib.af_unet_forward_twin(self._h, ptr(x), ptr(t), ptr(out), 2 * B, H, W, stream_ptr()),
+              "af_unet_forward_twin")
+        return out
+
     def unet_block_outputs(self, x: torch.Tensor, t: torch.Tensor, blocks=None) -> Dict[int, torch.Tensor]:
         """Outputs of U-Net blocks (forward order: input_blocks, middle_block, output_blocks) as fp32 NCHW tensors, one
         forward per requested block through the diagnostic tap (af_unet_set_tap).  Parity tests only."""

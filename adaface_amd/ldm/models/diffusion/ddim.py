@@ -156,8 +156,12 @@ class DDIMSampler(object):
         if unconditional_conditioning is None or guidance_scale == 1.:
             e_c, e_u = self.model.apply_model(x, t, c), None
         else:
-            e = self.model.apply_model(torch.cat([x] * 2), torch.cat([t] * 2),
-                                       self._twin_condition(c, unconditional_conditioning))
+            twin = self._twin_condition(c, unconditional_conditioning)
+            if hasattr(self.model, "apply_model_cfg_twin"):
+                # [x; x] without the concatenation: the UNet computes its context-independent prefix once (af_unet_forward_twin)
+                e = self.model.apply_model_cfg_twin(x, t, twin)
+            else:
+                e = self.model.apply_model(torch.cat([x] * 2), torch.cat([t] * 2), twin)
             e_c, e_u = e[:b], e[b:]
 
         alphas = self.model.alphas_cumprod if use_original_steps else self.ddim_alphas

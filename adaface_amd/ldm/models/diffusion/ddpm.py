@@ -31,7 +31,7 @@ class DiffusionWrapper(nn.Module):
         if conditioning_key not in (None, "crossattn"):
             raise NotImplementedError(f"conditioning_key '{conditioning_key}' is not used by SD-v1 txt2img")
 
-    def forward(self, x, t, c_concat: list = None, c_crossattn: list = None):
+    def forward(self, x, t, c_concat: list = None, c_crossattn: list = None, cfg_twin: bool = False):
         if self.conditioning_key is None:
             raise NotImplementedError("unconditional UNet is not on the path")
         c0 = c_crossattn[0]
@@ -39,6 +39,8 @@ class DiffusionWrapper(nn.Module):
             c_static_emb, c_in, extra_info = c0
         else:
             c_static_emb, c_in, extra_info = c0, None, None
+        if cfg_twin:
+            return self.diffusion_model(x, t, context=c_static_emb, context_in=c_in, extra_info=extra_info, cfg_twin=True)
         return self.diffusion_model(x, t, context=c_static_emb, context_in=c_in, extra_info=extra_info)
 
 
@@ -202,6 +204,20 @@ class LatentDiffusion(DDPM):
         if isinstance(x_recon, tuple) and not return_ids:
             return x_recon[0]
         return x_recon
+
+    def apply_model_cfg_twin(self, x_noisy, t, cond_twin):
+        """apply_model(torch.cat([x] * 2), torch.cat([t] * 2), cond_twin) -- the classifier-free-guidance call of
+        p_sample_ddim / p_sample_plms (ddim.py:236-247) -- without the concatenation: `cond_twin` is the condition of the
+        2B samples (cond first), x_noisy / t those of one half.  Returns eps of the 2B samples.  Not a reference method: the
+        drop-in samplers use it when the model has it, and fall back to apply_model on the concatenated batch otherwise."""
+        cond = cond_twin
+        if not isinstance(cond, dict):
+            if not isinstance(cond, list):
+                cond = [cond]
+            cond = {'c_crossattn': cond}
+        if 'c_crossattn' not in cond:
+            return self.apply_model(torch.cat([x_noisy] * 2), torch.cat([t] * 2), cond_twin)
+        return self.model(x_noisy, t, cfg_twin=True, **cond)
 
     # ---- decoder -----------------------------------------------------------------------------
     @torch.no_grad()

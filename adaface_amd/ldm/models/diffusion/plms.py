@@ -132,8 +132,11 @@ class PLMSSampler(object):
         def get_model_output(xx, tt):
             if unconditional_conditioning is None or unconditional_guidance_scale == 1.:
                 return self.model.apply_model(xx, tt, c)
-            e = self.model.apply_model(torch.cat([xx] * 2), torch.cat([tt] * 2),
-                                       self._twin_condition(c, unconditional_conditioning))
+            twin = self._twin_condition(c, unconditional_conditioning)
+            if hasattr(self.model, "apply_model_cfg_twin"):
+                e = self.model.apply_model_cfg_twin(xx, tt, twin)   # [x; x] without the concatenation (af_unet_forward_twin)
+            else:
+                e = self.model.apply_model(torch.cat([xx] * 2), torch.cat([tt] * 2), twin)
             return ops.lincomb([(e[b:], unconditional_guidance_scale), (e[:b], 0.0)], cfg=True)  # e_u + g (e_c - e_u)
 
         def get_x_prev_and_pred_x0(e, idx):

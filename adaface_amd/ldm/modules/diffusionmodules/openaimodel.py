@@ -131,9 +131,12 @@ class UNetModel(HipModule):
         return (ks, tuple(uniq), tuple(tuple(idx_n[i * M: i * M + ks * ks]) for i in range(len(uniq))))
 
     @torch.no_grad()
-    def forward(self, x, timesteps=None, context=None, y=None, context_in=None, extra_info=None, **kwargs):
+    def forward(self, x, timesteps=None, context=None, y=None, context_in=None, extra_info=None, cfg_twin=False, **kwargs):
         """x [B,C,H,W], timesteps [B], context [B*16,T,D] (layerwise) or [B,T,D]; returns eps [B,C,H,W] fp32.
-        Mirrors openaimodel.py:827-1052 for inference: `extra_info` keys read at :849-859."""
+        Mirrors openaimodel.py:827-1052 for inference: `extra_info` keys read at :849-859.
+        cfg_twin (not in the reference; used by this package's samplers): x / timesteps are ONE half of the
+        classifier-free-guidance batch, the context is that of [x; x] (cond first, ddim.py:236-247); returns eps for the
+        2B samples exactly as forward(torch.cat([x] * 2), torch.cat([t] * 2), context) would."""
         if y is not None:
             raise NotImplementedError("class-conditional UNet (num_classes) is not on the path")
         if timesteps is None or context is None:
@@ -147,7 +150,7 @@ class UNetModel(HipModule):
         if info.get("iter_type", "normal_recon") == "mix_hijk":
             raise NotImplementedError("iter_type 'mix_hijk' (separate k/v contexts) is a training-time option")
         eng = self.engine(x.device)
-        B = x.shape[0]
+        B = x.shape[0] * (2 if cfg_twin else 1)
         cache_ok = True
         if layerwise and info.get("apply_compel_cfg_prob", 0) > 0:
             context, cache_ok = self._compel_cfg(context.to(x.device), B, info)
@@ -159,7 +162,7 @@ class UNetModel(HipModule):
             eng.set_context(context.to(x.device), B, layerwise)
             object.__setattr__(self, "_ctx_key", key if cache_ok else None)
             object.__setattr__(self, "_ctx_ref", context)
-        out = eng.unet_forward(x, timesteps.to(x.device))
+        out = (eng.unet_forward_twin if cfg_twin else eng.unet_forward)(x, timesteps.to(x.device))
         if extra_info is not None:
             # the reference writes the (here empty) distillation capture into the caller's dict (:1031-1035)
             extra_info["ca_layers_activations"] = {k: {} for k in ("outfeat", "attn", "attnscore", "q")}

@@ -94,6 +94,14 @@ int af_set_context(af_handle* h, const float* ctx_dev, int Bf, int n_tokens, int
  * t_dev [Bf] int64, eps_dev [Bf,Cout,H,W] fp32 NCHW.  Uses the context set above. */
 int af_unet_forward(af_handle* h, const float* x_dev, const int64_t* t_dev, float* eps_dev, int Bf, int H, int W,
                     void* stream);
+/* The same forward on the classifier-free-guidance batch [x; x], [t; t] that p_sample_ddim / p_sample_plms build with
+ * torch.cat([x] * 2) (ddim.py:236-247, plms.py:181-192): x_dev [Bf/2,Cin,H,W], t_dev [Bf/2], eps_dev [Bf,Cout,H,W]
+ * (first half = the first Bf/2 contexts of af_set_context, i.e. cond first as the reference), Bf even.  Everything in
+ * front of the first cross-attention (time embedding, conv_in, input_blocks[1]'s ResBlock, the first transformer's
+ * GroupNorm / proj_in / self-attention) is identical for the two halves, so it is computed for Bf/2 samples and copied.
+ * Same result as af_unet_forward on the concatenated inputs up to the summation order of shape-dependent kernel plans. */
+int af_unet_forward_twin(af_handle* h, const float* x_dev, const int64_t* t_dev, float* eps_dev, int Bf, int H, int W,
+                         void* stream);
 
 /* ---- conditioning producer: CLIP text tower (names "cond_stage_model.transformer.text_model.<k>") ----
  * af_clip_embed_tokens = CLIPTextEmbeddings.token_embedding (encoders/modules.py:207-208): ids_dev [n] int64 ->

@@ -19,6 +19,7 @@ ap.add_argument("--lib", default="")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--fp8", action="store_true")
 ap.add_argument("--knob", action="append", default=[])
+ap.add_argument("--twin", action="store_true", help="af_unet_forward_twin on x[:8] (the CFG batch [x; x]) instead of af_unet_forward")
 args = ap.parse_args()
 if args.lib:
     _lib._LIB_PATH = Path(args.lib).resolve()
@@ -47,21 +48,26 @@ t = torch.full((16,), 500, dtype=torch.long, device=dev)
 ctx = torch.randn(16 * 16, 77, 768, generator=g).to(dev)
 eng.set_context(ctx, 16, layerwise=True)
 out = torch.empty_like(x)
+if args.twin:
+    xh, th = x[:8].contiguous(), t[:8].contiguous()
+    fwd = lambda x_, t_, o_: eng.unet_forward_twin(xh, th, o_)
+else:
+    fwd = eng.unet_forward
 for _ in range(3):
-    eng.unet_forward(x, t, out)
+    fwd(x, t, out)
 torch.cuda.synchronize()
 best = 1e9
 for rnd in range(3):
     t0 = time.perf_counter()
     for _ in range(args.reps):
-        eng.unet_forward(x, t, out)
+        fwd(x, t, out)
     torch.cuda.synchronize()
     best = min(best, (time.perf_counter() - t0) / args.reps)
 # per-class kernel time of one forward (HIP-event brackets around every launch: slows the forward, classes comparable)
 lib = _lib.load()
 lib.af_prof_reset(); lib.af_prof_set_stride(1) if hasattr(lib, "af_prof_set_stride") else None
 lib.af_prof_enable(0x3ff)
-eng.unet_forward(x, t, out)
+fwd(x, t, out)
 torch.cuda.synchronize()
 lib.af_prof_enable(0)
 n = 10
@@ -70,4 +76,4 @@ lib.af_prof_collect(n, ms, la, fl, by)
 names = ["gemm_other", "attention", "groupnorm", "layernorm", "other", "pp160_gather", "pp160_plain", "pp128", "fp8", "halo8"]
 print("   per-class ms per forward: " + ", ".join(f"{names[i]} {ms[i]:.2f} ({la[i]})" for i in range(n) if la[i])
       + f" | gemm total {ms[0] + ms[5] + ms[6] + ms[7] + ms[8] + ms[9]:.2f}")
-print(f"{args.lib or 'HEAD'}{' fp8' if args.fp8 else ''} {' '.join(args.knob)}: UNet forward Bf=16: {best * 1e3:.3f} ms  (-> {8 / (50 * best + 0.026):.2f} images/s at 50 steps + 26 ms VAE)")
+print(f"{args.lib or 'HEAD'}{' fp8' if args.fp8 else ''}{' twin' if args.twin else ''} {' '.join(args.knob)}: UNet forward Bf=16: {best * 1e3:.3f} ms  (-> {8 / (50 * best + 0.026):.2f} images/s at 50 steps + 26 ms VAE)")

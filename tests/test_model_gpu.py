@@ -335,6 +335,38 @@ def test_sd15_unet_batch_consistency(gpu, report):
         eng.close()
 
 
+@pytest.mark.parametrize("dtype,B", [("f32", 2), ("bf16", 8), ("bf16", 1)])
+def test_sd15_unet_forward_twin(gpu, report, dtype, B):
+    """af_unet_forward_twin(x, t) == af_unet_forward(cat([x] * 2), cat([t] * 2)): the classifier-free-guidance batch with
+    its context-independent prefix (time embedding, conv_in, the first ResBlock, the first transformer up to the
+    cross-attention) computed once and copied.  f32: equal up to summation order (1e-5); bf16: the half-batch launches of
+    the prefix may be planned differently (other tile / K slicing), so the two forwards are held to the bf16 bar against
+    each other -- and the two halves of the twin forward must differ (they see different contexts)."""
+    from adaface_amd.engine import Engine
+    from adaface_amd.synth import synth_weights_into
+    cfg = O.SD15_UNET
+    g = torch.Generator().manual_seed(41 + B)
+    x = torch.randn(B, 4, 64, 64, generator=g).to(gpu)
+    t = torch.randint(0, 1000, (B,), generator=g).to(gpu)            # distinct timesteps per sample
+    ctx = torch.randn(2 * B * 16, 77, cfg.context_dim, generator=g).to(gpu)
+    eng = Engine(dtype=dtype, unet=_unet_kwargs(cfg))
+    synth_weights_into(eng, O.unet_param_shapes(cfg), seed=42, device=gpu)
+    eng.set_context(ctx, 2 * B, layerwise=True)
+    full = eng.unet_forward(torch.cat([x, x]), torch.cat([t, t]))
+    twin = eng.unet_forward_twin(x, t)
+    assert twin.shape == full.shape and torch.isfinite(twin).all()
+    scale = full.abs().max().item()
+    err = (twin - full).abs().max().item() / scale
+    report(f"sd15_unet forward_twin vs forward(cat) B={B} [{dtype}]", err, scale, BATCH_TOL[dtype])
+    assert err <= BATCH_TOL[dtype], err
+    assert (twin[:B] - twin[B:]).abs().max().item() > 1e-3 * scale
+    from adaface_amd._lib import AfError, check, ptr, stream_ptr
+    with pytest.raises(AfError):                                      # an odd batch is not [x; x]
+        out = torch.empty(3, 4, 64, 64, device=gpu)
+        check(eng._lib.af_unet_forward_twin(eng._h, ptr(x), ptr(t), ptr(out), 3, 64, 64, stream_ptr()), "twin")
+    eng.close()
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_sd15_vae_batch_consistency(gpu, report, dtype):
     """VAE decode of the benchmark's 8 latents in one call vs each latent alone (float image and uint8 frame)."""
