@@ -88,11 +88,13 @@ _SIGS = [
     ("af_op_conv2d", C.c_int, [C.c_int, _P, _P, _P, _P, _P] + [C.c_int] * 9 + [_P]),
     ("af_op_linear", C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     ("af_op_groupnorm", C.c_int, [C.c_int, _P, _P, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    ("af_op_conv_gn", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_int, _P, _P] + [C.c_int] * 5 + [_P]),
     ("af_set_fp8", C.c_int, [_P, C.c_int]),
     ("af_fp8_gemm_launches", C.c_int64, []),
     ("af_halo8_launches", C.c_int64, []),
     ("af_rowpanel_launches", C.c_int64, []),
     ("af_up_phase4_launches", C.c_int64, []),
+    ("af_gn_producer_launches", C.c_int64, []),
     ("af_op_conv2d_fp8", C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 10 + [_P]),
     ("af_op_groupnorm_fp8", C.c_int, [_P, _P, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("af_op_layernorm_fp8", C.c_int, [_P, _P, _P, C.c_float, _P, C.c_int64, C.c_int, C.c_int, _P]),
@@ -148,6 +150,7 @@ def plan_counts(reset: bool = False) -> dict:
     out["halo8"] = int(lib.af_halo8_launches())
     out["rowpanel"] = int(lib.af_rowpanel_launches())
     out["up_phase4"] = int(lib.af_up_phase4_launches())
+    out["gn_producer"] = int(lib.af_gn_producer_launches())
     if reset:
         lib.af_gemm_plan_counts_reset()
     return out

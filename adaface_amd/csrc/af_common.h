@@ -88,6 +88,7 @@ struct AfKnobs {
   int conv_halo8;           // AF_CONV_HALO8           0 = 3x3 / stride-1 convs stay on the gathering eight-wave kernel (no LDS halo)
   int conv_fast_taps;       // AF_CONV_FAST_TAPS       0 = ping-pong convs recompute every tap's bounds check in the staging phase
   int pp_stagger;           // AF_PP_STAGGER           merged schedule: 1 = the two wave groups issue their LDS-DMA pieces behind alternate MFMAs
+  int gn_producer;          // AF_GN_PRODUCER          0 = GroupNorm always runs its own statistics pass (no sums from the producer convolution)
   int conv_up_phase4;       // AF_CONV_UP_PHASE4       0 = upsampled 3x3 convolutions gather all nine taps from the upsampled map
   int pp_sched;             // AF_PP_SCHED             eight-wave kernel: 0 = round-1 compute phase (two K halves, a full LDS drain
                             //                         after each), 1 = block-ordered compute phase, 2 = merged (no staging phase)
@@ -288,6 +289,12 @@ struct ConvGemmParams {
   //   STORED map, output pixel (2 y + dy, 2 x + dx) of the [B][2 Hs][2 Ws] map
   const void* W_up4;
   int phase4;
+  // GroupNorm statistics from the producer (eight-wave kernels, bf16 outputs, one K slice): besides its output the
+  // convolution writes, per 64-row slab of a sample and per group of gn_cpg channels, the sum and the sum of squares of
+  // the bf16-ROUNDED values it stored, in the layout gn_apply_kernel folds: gn_stats_out[((b * npart + slab) * 32 + group) * 2],
+  // npart = Ho * Wo / 64 (fixed order, no atomics).  The consumer GroupNorm then needs no statistics pass over the tensor.
+  float* gn_stats_out;
+  int gn_cpg;
 };
 
 struct AfGemmPlan {

@@ -669,6 +669,38 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
       }
     }
     if (!slab) wflush();
+    if (p.gn_stats_out && !slab && !geglu) {
+      // GroupNorm statistics of the producer (ConvGemmParams::gn_stats_out): the wave's 64 x HNo outputs still sit, bf16-rounded
+      // as stored, in its transposition tile.  Lane = a pair of adjacent columns (never straddles a group: gn_cpg is even),
+      // 64 conflict-free 4-byte reads down the rows; then gn_cpg / 2 consecutive lanes per group are summed through the tile.
+      const int mslab = m0 + wq * 64;
+      if (mslab < p.M) {              // (M % 64 == 0: a slab is all rows or none)
+        float s = 0.f, q = 0.f;
+        if (lane < HNo / 2) {
+#pragma unroll 8
+          for (int r = 0; r < 64; ++r) {
+            const unsigned w = *reinterpret_cast<const unsigned*>(wtile + r * wpitch + lane * 4);
+            const float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xffff0000u);
+            s += a + b;
+            q += a * a + b * b;
+          }
+        }
+        float2* scr = reinterpret_cast<float2*>(wtile);   // (LDS operations of one wave execute in order)
+        scr[lane] = float2{s, q};
+        const int hpg = p.gn_cpg >> 1, ng = (HNo / 2) / hpg;
+        if (lane < ng) {
+          float a = 0.f, b = 0.f;
+          for (int t = 0; t < hpg; ++t) {
+            const float2 v = scr[lane * hpg + t];
+            a += v.x;
+            b += v.y;
+          }
+          const int hw = 1 << p.howo_shift;
+          const long part = ((long)(mslab >> p.howo_shift) * (hw >> 6) + ((mslab & (hw - 1)) >> 6)) * 32 + (ncol0 + g * HNo) / p.gn_cpg + lane;
+          *reinterpret_cast<float2*>(p.gn_stats_out + part * 2) = float2{a, b};
+        }
+      }
+    }
     return;
   }
   constexpr int ITEMS = BN / 32;                    // 8-column vectors per thread and pass (GEGLU: half of them)
@@ -2266,7 +2298,7 @@ AfGemmPlan g_af_last_plan = {0, 1, 0, 0, 1};
 // [7] launches that sliced K (counted in their tile's slot as well), [8] / [9] ping-pong launches with the LayerNorm
 // consumer / statistics-producer epilogue, [10] ping-pong launches with fp8 operands, [11] eight-wave halo launches
 // (counted under tile 5 as well), [12] row-panel GEGLU launches (counted under their planned tile as well)
-long g_af_plan_counts[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [13]: phase-decomposed upsampled convolutions
+long g_af_plan_counts[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [13]: phase-decomposed upsampled convolutions, [14]: GroupNorm-statistics producers
 
 
 // tile: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64
@@ -2538,6 +2570,14 @@ static int launch_conv_gemm_fp8(ConvGemmParams p, hipStream_t stream, const AfGe
   }
   p.group_m = pl.group_m > 0 ? pl.group_m : 1;
   p.pp_epilogue = g_af_knobs.pp_direct < 0 ? 0 : (g_af_knobs.pp_direct ? 2 : 1);
+  if (p.gn_stats_out) {
+    if (!af_conv_gn_stats_ok(p, pl, p.gn_cpg)) {
+      af_set_error_msg("conv_gemm fp8: GroupNorm partial sums asked of a launch that cannot write them");
+      return -1;
+    }
+    p.pp_epilogue = 2;
+    g_af_plan_counts[14] += 1;
+  }
   p.k_tap_inner = 1;
   p.fast_taps = g_af_knobs.conv_fast_taps;
   p.pp_stagger = g_af_knobs.pp_stagger;
@@ -2660,6 +2700,17 @@ static int launch_up_phase4(ConvGemmParams p, hipStream_t stream) {
   return bn == 160 ? launch_pp_one<160, 0, true, false, 2>(p, grid, stream) : launch_pp_one<128, 0, true, false, 2>(p, grid, stream);
 }
 
+// GroupNorm partial sums from the epilogue: the eight-wave kernels (gathering / LDS-halo / fp8) with bf16 outputs in ONE K
+// slice, 3x3 / stride 1 / no upsampling (so neither the row-panel nor the phase-decomposed launches apply), whole 64-row
+// slabs inside one sample, every group inside one wave's column half
+bool af_conv_gn_stats_ok(const ConvGemmParams& p, const AfGemmPlan& pl, int cpg) {
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  const int hn = pl.tile == 5 ? 80 : 64;
+  return g_af_knobs.gn_producer && pl.tile >= 4 && pl.splitk <= 1 && p.ks == 3 && p.stride == 1 && p.up == 0 &&
+         p.epilogue != AF_EPI_GEGLU && !p.ln_stats && !p.ln_stats_out && cpg >= 2 && cpg % 2 == 0 && hn % cpg == 0 &&
+         p.N == 32 * cpg && pow2(p.Ho * p.Wo) && p.Ho * p.Wo >= 64 && p.M % 64 == 0;
+}
+
 template <typename T>
 int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t stream, const AfGemmPlan* plan, void* ws) {
   constexpr int BK = 128 / sizeof(T);
@@ -2714,6 +2765,14 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   }
   p.group_m = pl.group_m > 0 ? pl.group_m : 1;
   p.pp_epilogue = g_af_knobs.pp_direct < 0 ? 0 : (g_af_knobs.pp_direct ? 2 : 1);
+  if (p.gn_stats_out) {
+    if (sizeof(T) != 2 || batch != 1 || !af_conv_gn_stats_ok(p, pl, p.gn_cpg)) {
+      af_set_error_msg("conv_gemm: GroupNorm partial sums asked of a launch that cannot write them (ask af_conv_gn_stats_ok first)");
+      return -1;
+    }
+    p.pp_epilogue = 2;   // they are summed from the wave-private transposition tile of the direct epilogue
+    g_af_plan_counts[14] += 1;
+  }
   p.k_tap_inner = (p.ks > 1 && g_af_knobs.conv_tap_inner) ? 1 : 0;
   p.fast_taps = g_af_knobs.conv_fast_taps;
   p.pp_stagger = g_af_knobs.pp_stagger;

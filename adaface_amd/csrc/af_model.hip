@@ -53,7 +53,7 @@ AfKnobs g_af_knobs = {
     knob_env("AF_PP_DIRECT", -1),      knob_env("AF_ATTN_W4", 1),         knob_env("AF_ATTN_RING", 1),
     knob_env("AF_GN_SMALL", 1),        knob_env("AF_GN_FOLD", 1),         knob_env("AF_CONV_TAP_INNER", 1),
     knob_env("AF_LN_FUSE", 1),         knob_env("AF_GEGLU_ROWPANEL", 3), knob_env("AF_CONV_HALO8", 1), knob_env("AF_CONV_FAST_TAPS", 1),
-    knob_env("AF_PP_STAGGER", 1),      knob_env("AF_CONV_UP_PHASE4", 1),
+    knob_env("AF_PP_STAGGER", 1),      knob_env("AF_GN_PRODUCER", 1),     knob_env("AF_CONV_UP_PHASE4", 1),
     knob_env("AF_PP_SCHED", 2)};
 static const AfKnobs g_af_knobs_initial = g_af_knobs;
 static int* knob_slot(const char* name) {
@@ -63,7 +63,7 @@ static int* knob_slot(const char* name) {
       {"gemm_tile", &AfKnobs::gemm_tile}, {"gemm_splitk", &AfKnobs::gemm_splitk}, {"gemm_groupm", &AfKnobs::gemm_groupm},
       {"gemm_dma", &AfKnobs::gemm_dma}, {"pp_direct", &AfKnobs::pp_direct}, {"attn_w4", &AfKnobs::attn_w4}, {"attn_ring", &AfKnobs::attn_ring},
       {"gn_small", &AfKnobs::gn_small}, {"gn_fold", &AfKnobs::gn_fold}, {"conv_tap_inner", &AfKnobs::conv_tap_inner}, {"ln_fuse", &AfKnobs::ln_fuse},
-      {"geglu_rowpanel", &AfKnobs::geglu_rowpanel}, {"conv_halo8", &AfKnobs::conv_halo8}, {"conv_fast_taps", &AfKnobs::conv_fast_taps}, {"pp_stagger", &AfKnobs::pp_stagger}, {"conv_up_phase4", &AfKnobs::conv_up_phase4}, {"pp_sched", &AfKnobs::pp_sched}};
+      {"geglu_rowpanel", &AfKnobs::geglu_rowpanel}, {"conv_halo8", &AfKnobs::conv_halo8}, {"conv_fast_taps", &AfKnobs::conv_fast_taps}, {"pp_stagger", &AfKnobs::pp_stagger}, {"gn_producer", &AfKnobs::gn_producer}, {"conv_up_phase4", &AfKnobs::conv_up_phase4}, {"pp_sched", &AfKnobs::pp_sched}};
   if (!name) return nullptr;
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) return &(g_af_knobs.*(t.m));
@@ -143,6 +143,10 @@ struct Act {  // NHWC activation view
   int B = 0, H = 0, W = 0, C = 0;
   int ld = 0;  // elements between pixels
   bool f8 = false;  // e4m3 bytes (value * 2^AF_FP8_ACT_SHIFT), consumed by an fp8 convolution only
+  // GroupNorm partial sums [B][gn_npart][32][2] written by the convolution that produced this tensor (ConvGemmParams::
+  // gn_stats_out); valid for exactly the B samples and C channels of this view
+  const float* gn_part = nullptr;
+  int gn_npart = 0;
   long npix() const { return (long)B * H * W; }
 };
 
@@ -280,6 +284,10 @@ struct af_handle {
   bool fp8_on = false;         // af_set_fp8: ResBlock 3x3 convolutions of the UNet on the block-scaled fp8 MFMA
   bool fp8_dirty = true;       // fp8 weight twins must be (re)quantised
   bool up4_dirty = true;       // phase weights of the upsampled convolutions must be (re)summed
+  // GroupNorm partial sums of a block OUTPUT (ResBlock conv2 -> the GroupNorm that opens the next layer): outlives the
+  // arena scope of the producer; one such tensor is live at a time.  Sized by the dry run.
+  float* gn_carry = nullptr;
+  size_t gn_carry_bytes = 0, gn_carry_need = 0;
 
   // diagnostic tap (af_unet_set_tap): block whose output the next forwards also write, fp32 NCHW
   int tap_index = -1;
@@ -826,9 +834,12 @@ struct Runner {
     if (pl.tile < 4 || pl.splitk > 1 || pl.halo_tw) return 0;
     return (p.N / (pl.tile == 5 ? 160 : 128)) * 2;
   }
+  // want_gn: 1 = also write the GroupNorm partial sums of `out` into the arena (consumer inside the caller's arena scope),
+  // 2 = into the handle's carry buffer (consumer = the next layer); out.gn_part is set when the launch can do it
   int conv(const Linear& L, const Act& x, Act& out, int stride, int up, const Act* residual, const void* rowbias,
-           int ldrb, int n_valid = -1, int pad = -1, const LnArgs* ln = nullptr) {
+           int ldrb, int n_valid = -1, int pad = -1, const LnArgs* ln = nullptr, int want_gn = 0) {
     AF_TRY(check(out));
+    out.gn_part = nullptr; out.gn_npart = 0;
     ConvGemmParams p;
     conv_params(p, L, x, out, stride, up, residual, rowbias, ldrb, n_valid, pad);
     if (ln) {
@@ -842,6 +853,26 @@ struct Runner {
     if (x.f8 && (!L.w8 || ln)) { af_set_error_msg("conv: e4m3 input without an fp8 weight twin"); return AF_ERR_STATE; }
     const AfGemmPlan pl = af_plan_conv_gemm(p, 1, (int)esize(dt));
     if (x.f8 && pl.tile < 4) { af_set_error_msg("conv: e4m3 input on a shape without an fp8 plan"); return AF_ERR_STATE; }
+    if (want_gn && dt == AF_DTYPE_BF16 && out.C % 32 == 0 && out.C == p.N && af_conv_gn_stats_ok(p, pl, out.C / 32)) {
+      const int npart = out.H * out.W / 64;
+      const size_t bytes = (size_t)out.B * npart * 32 * 2 * sizeof(float);
+      float* st = nullptr;
+      if (want_gn == 1) {
+        st = reinterpret_cast<float*>(A.alloc(bytes));
+        if (!st) { af_set_error_msg("arena exhausted (GroupNorm partial sums)"); return AF_ERR_STATE; }
+      } else if (dry) {
+        if (bytes > h->gn_carry_need) h->gn_carry_need = bytes;
+        st = reinterpret_cast<float*>(1);          // (sizing pass: only "not null" matters)
+      } else if (bytes <= h->gn_carry_bytes) {
+        st = h->gn_carry;
+      }
+      if (st) {
+        p.gn_stats_out = st;
+        p.gn_cpg = out.C / 32;
+        out.gn_part = st;
+        out.gn_npart = npart;
+      }
+    }
     void* ws = nullptr;
     if (pl.splitk > 1) {
       const size_t mk = A.mark();
@@ -863,12 +894,14 @@ struct Runner {
     if (!ws) { af_set_error_msg("arena exhausted (groupnorm workspace)"); return AF_ERR_STATE; }
     if (dry) return 0;
     if (x.C != N.C) { af_set_error_msg("groupnorm: C mismatch %d vs %d", x.C, N.C); return AF_ERR_INVALID; }
+    // (statistics already summed by the convolution that produced x: no pass over the tensor for them)
+    const float* pre = g_af_knobs.gn_producer ? x.gn_part : nullptr;
     if (y.f8)
       return af_launch_groupnorm<bf16>(x.p, (long)HW * x.ld, x.ld, x.B, HW, x.C, N.gamma, N.beta, N.eps, silu, y.p,
-                                       (long)HW * y.ld, y.ld, ws, s, (float)(1 << AF_FP8_ACT_SHIFT));
+                                       (long)HW * y.ld, y.ld, ws, s, (float)(1 << AF_FP8_ACT_SHIFT), pre, x.gn_npart);
     return DISPATCH(dt,
                     af_launch_groupnorm<bf16>(x.p, (long)HW * x.ld, x.ld, x.B, HW, x.C, N.gamma, N.beta, N.eps, silu,
-                                              y.p, (long)HW * y.ld, y.ld, ws, s),
+                                              y.p, (long)HW * y.ld, y.ld, ws, s, 0.f, pre, x.gn_npart),
                     af_launch_groupnorm<float>(x.p, (long)HW * x.ld, x.ld, x.B, HW, x.C, N.gamma, N.beta, N.eps, silu,
                                                y.p, (long)HW * y.ld, y.ld, ws, s));
   }
@@ -913,7 +946,8 @@ static int run_resblock(Runner& R, const ResBlockW& w, const Act& x, Act& out, c
   Act t1 = R.fp8_capable(w.c1, x, t2) ? R.alloc_act8(x.B, x.H, x.W, x.C) : R.alloc_act(x.B, x.H, x.W, x.C);
   AF_TRY(R.groupnorm(w.n1, x, t1, 1));
   const void* rb = (emb_all && w.emb_off >= 0) ? R.elem_ptr(const_cast<void*>(emb_all), w.emb_off) : nullptr;
-  AF_TRY(R.conv(w.c1, t1, t2, 1, 0, nullptr, rb, emb_ld));
+  // (conv1 also sums the GroupNorm statistics of its output where its kernel can: n2 then makes no pass for them)
+  AF_TRY(R.conv(w.c1, t1, t2, 1, 0, nullptr, rb, emb_ld, -1, -1, nullptr, 1));
   Act t3 = R.fp8_capable(w.c2, t2, out) ? R.alloc_act8(x.B, x.H, x.W, w.cout) : R.alloc_act(x.B, x.H, x.W, w.cout);
   AF_TRY(R.groupnorm(w.n2, t2, t3, 1));
   Act sk = x;
@@ -921,7 +955,8 @@ static int run_resblock(Runner& R, const ResBlockW& w, const Act& x, Act& out, c
     sk = R.alloc_act(x.B, x.H, x.W, w.cout);
     AF_TRY(R.conv(w.skip, x, sk, 1, 0, nullptr, nullptr, 0));
   }
-  AF_TRY(R.conv(w.c2, t3, out, 1, 0, &sk, nullptr, 0));
+  // (... and conv2 those of the block output, for the GroupNorm that opens the next layer -- a transformer or a ResBlock)
+  AF_TRY(R.conv(w.c2, t3, out, 1, 0, &sk, nullptr, 0, -1, -1, nullptr, 2));
   R.A.release(mk);
   return 0;
 }
@@ -1194,6 +1229,18 @@ static int ensure_up4_twins(af_handle* h, hipStream_t s) {
     }
     AF_TRY(af_launch_up_phase4_weights(L->w, L->rows_pad, L->cin_pad, L->ldw, L->w_up4, s));
   }
+  return 0;
+}
+
+// carry buffer of the GroupNorm partial sums of block outputs (sized by the dry run that precedes every forward)
+static int ensure_gn_carry(af_handle* h, hipStream_t s) {
+  if (h->gn_carry_need <= h->gn_carry_bytes) return 0;
+  HIP_CHECK_RET(hipStreamSynchronize(s));
+  void* p = nullptr;
+  if (hipMalloc(&p, h->gn_carry_need) != hipSuccess) { af_set_error_msg("hipMalloc of the GroupNorm carry buffer failed"); return AF_ERR_HIP; }
+  h->owned.push_back(p);          // (the smaller predecessor, if any, stays owned until af_destroy: a few hundred KB)
+  h->gn_carry = reinterpret_cast<float*>(p);
+  h->gn_carry_bytes = h->gn_carry_need;
   return 0;
 }
 
@@ -1901,6 +1948,7 @@ static int unet_forward_entry(af_handle* h, const float* x_dev, const int64_t* t
   h->arena.dry = false;
   if (rc) return rc;
   if (h->arena.peak > h->arena.cap) { HIP_CHECK_RET(hipStreamSynchronize(s)); AF_TRY(ensure_arena(h, h->arena.peak)); }
+  AF_TRY(ensure_gn_carry(h, s));
   return unet_forward_impl(h, s, x_dev, t_dev, eps_dev, Bf, H, W, twin);
 }
 int af_unet_forward(af_handle* h, const float* x_dev, const int64_t* t_dev, float* eps_dev, int Bf, int H, int W,
@@ -1972,6 +2020,7 @@ int af_clip_text_forward(af_handle* h, const float* inputs_embeds_dev, int Bn, i
   h->arena.dry = false;
   if (rc) return rc;
   if (h->arena.peak > h->arena.cap) { HIP_CHECK_RET(hipStreamSynchronize(s)); AF_TRY(ensure_arena(h, h->arena.peak)); }
+  AF_TRY(ensure_gn_carry(h, s));
   return clip_forward_impl(h, s, inputs_embeds_dev, Bn, T, w_prev, w_last, out_dev);
 }
 
@@ -1989,6 +2038,7 @@ int af_clip_text_forward3(af_handle* h, const float* inputs_embeds_dev, int Bn, 
   h->arena.dry = false;
   if (rc) return rc;
   if (h->arena.peak > h->arena.cap) { HIP_CHECK_RET(hipStreamSynchronize(s)); AF_TRY(ensure_arena(h, h->arena.peak)); }
+  AF_TRY(ensure_gn_carry(h, s));
   return clip_forward_impl(h, s, inputs_embeds_dev, Bn, T, w_prev, w_last, out_dev, w_prev2);
 }
 
@@ -2022,6 +2072,7 @@ int af_vae_decode(af_handle* h, const float* z_dev, float scale_factor, float* i
   h->arena.dry = false;
   if (rc) return rc;
   if (h->arena.peak > h->arena.cap) { HIP_CHECK_RET(hipStreamSynchronize(s)); AF_TRY(ensure_arena(h, h->arena.peak)); }
+  AF_TRY(ensure_gn_carry(h, s));
   return vae_decode_impl(h, s, z_dev, scale_factor, img_dev, u8_dev, B, H, W);
 }
 
@@ -2039,6 +2090,7 @@ int af_vae_encode(af_handle* h, const float* x_dev, float* moments_dev, int B, i
   h->arena.dry = false;
   if (rc) return rc;
   if (h->arena.peak > h->arena.cap) { HIP_CHECK_RET(hipStreamSynchronize(s)); AF_TRY(ensure_arena(h, h->arena.peak)); }
+  AF_TRY(ensure_gn_carry(h, s));
   return vae_encode_impl(h, s, x_dev, moments_dev, B, H, W);
 }
 
@@ -2099,13 +2151,14 @@ int af_gemm_plan_counts(int64_t* counts10) {
   return AF_OK;
 }
 int af_gemm_plan_counts_reset(void) {
-  for (int i = 0; i < 14; ++i) g_af_plan_counts[i] = 0;
+  for (int i = 0; i < 15; ++i) g_af_plan_counts[i] = 0;
   return AF_OK;
 }
 int64_t af_fp8_gemm_launches(void) { return g_af_plan_counts[10]; }
 int64_t af_halo8_launches(void) { return g_af_plan_counts[11]; }
 int64_t af_rowpanel_launches(void) { return g_af_plan_counts[12]; }
 int64_t af_up_phase4_launches(void) { return g_af_plan_counts[13]; }
+int64_t af_gn_producer_launches(void) { return g_af_plan_counts[14]; }
 int af_set_fp8(af_handle* h, int on) {
   if (!h) { af_set_error_msg("af_set_fp8: null handle"); return AF_ERR_INVALID; }
   if (on && h->dtype != AF_DTYPE_BF16) { af_set_error_msg("af_set_fp8: the fp8 convolutions extend the bf16 mode (handle is f32)"); return AF_ERR_STATE; }

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                                                         const float* __restrict__ beta, int silu,
                                                         T* __restrict__ y, long y_batch_stride, int ldy,
                                                         const float* __restrict__ partial, int nchunk, double count,
-                                                        float eps, float fp8_mul) {
+                                                        float eps, float fp8_mul, int npart) {
   constexpr int EPC = 16 / sizeof(T);
   __shared__ __attribute__((aligned(16))) float s_a[GN_MAX_C];
   __shared__ __attribute__((aligned(16))) float s_b[GN_MAX_C];
@@ -158,10 +158,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   if (partial) {
     // finalize folded in (few chunks): every block combines its sample's partial sums itself, in the same fixed
     // order as gn_finalize_kernel, so the statistics are bitwise identical across blocks and launches
+    // (npart: partial sums per sample -- the chunks of gn_stats_kernel, or the 64-row slabs of a producer convolution)
     const int g = tid & 31, sl = tid >> 5;
     double a = 0.0, q = 0.0;
-    for (int c = sl; c < nchunk; c += 8) {
-      const float* src = partial + (((long)b * nchunk + c) * GN_GROUPS + g) * 2;
+    for (int c = sl; c < npart; c += 8) {
+      const float* src = partial + (((long)b * npart + c) * GN_GROUPS + g) * 2;
       a += (double)src[0];
       q += (double)src[1];
     }
@@ -471,7 +472,7 @@ size_t af_gn_workspace_bytes(int B, int HW) {
 template <typename T>
 int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn, const float* gamma,
                         const float* beta, float eps, int silu, void* y, long y_bs, int ldy, void* workspace,
-                        hipStream_t stream, float fp8_mul) {
+                        hipStream_t stream, float fp8_mul, const float* pre_partial, int pre_npart) {
   constexpr int EPC = 16 / sizeof(T);
   if (fp8_mul != 0.f && sizeof(T) != 2) { af_set_error_msg("groupnorm: fp8 output needs the bf16 storage mode"); return -1; }
   if (Cn % GN_GROUPS != 0 || Cn % EPC != 0 || Cn > GN_MAX_C || ldx % EPC != 0 || ldy % EPC != 0) {
@@ -492,17 +493,25 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
   }
   int P;
   const int nchunk = af_gn_chunking(HW, B, &P);
-  float* partial = reinterpret_cast<float*>(workspace);
-  float* stats = partial + (size_t)B * nchunk * GN_GROUPS * 2;
-  hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nchunk, B), dim3(256), 0, stream,
-                     reinterpret_cast<const T*>(x), x_bs, ldx, HW, Cn, P, partial, nchunk);
+  const float* partial = reinterpret_cast<float*>(workspace);
+  float* stats = reinterpret_cast<float*>(workspace) + (size_t)B * nchunk * GN_GROUPS * 2;
+  int npart = nchunk;
+  if (pre_partial) {
+    // the producer convolution wrote [B][pre_npart][32][2] partial sums of the values it stored (ConvGemmParams::gn_stats_out):
+    // no statistics pass over x at all
+    partial = pre_partial;
+    npart = pre_npart;
+  } else {
+    hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nchunk, B), dim3(256), 0, stream,
+                       reinterpret_cast<const T*>(x), x_bs, ldx, HW, Cn, P, reinterpret_cast<float*>(workspace), nchunk);
+  }
   const double count = (double)HW * (double)(Cn / GN_GROUPS);
   const bool fold_ok = g_af_knobs.gn_fold != 0;
-  const bool fold = fold_ok && nchunk <= 64;  // few chunks: the apply blocks finalize the statistics themselves
-  if (!fold) hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, partial, nchunk, count, eps, stats);
+  const bool fold = fold_ok && npart <= 64;  // few chunks: the apply blocks finalize the statistics themselves
+  if (!fold) hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, partial, npart, count, eps, stats);
   hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nchunk, B), dim3(256), 0, stream,
                      reinterpret_cast<const T*>(x), x_bs, ldx, HW, Cn, P, stats, gamma, beta, silu,
-                     reinterpret_cast<T*>(y), y_bs, ldy, fold ? partial : nullptr, nchunk, count, eps, fp8_mul);
+                     reinterpret_cast<T*>(y), y_bs, ldy, fold ? partial : nullptr, nchunk, count, eps, fp8_mul, npart);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -536,9 +545,9 @@ int af_launch_layernorm(const void* x, int ldx, long rows, int Cn, const float* 
 }
 
 template int af_launch_groupnorm<bf16>(const void*, long, int, int, int, int, const float*, const float*, float,
-                                       int, void*, long, int, void*, hipStream_t, float);
+                                       int, void*, long, int, void*, hipStream_t, float, const float*, int);
 template int af_launch_groupnorm<float>(const void*, long, int, int, int, int, const float*, const float*, float,
-                                        int, void*, long, int, void*, hipStream_t, float);
+                                        int, void*, long, int, void*, hipStream_t, float, const float*, int);
 template int af_launch_layernorm<bf16>(const void*, int, long, int, const float*, const float*, float, void*, int,
                                        hipStream_t, float);
 template int af_launch_layernorm<float>(const void*, int, long, int, const float*, const float*, float, void*,

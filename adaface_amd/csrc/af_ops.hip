@@ -242,6 +242,60 @@ int af_op_groupnorm(int dtype, const float* x_dev, const float* gamma_dev, const
   return 0;
 }
 
+// 3x3 / stride-1 convolution (bf16) followed by GroupNorm(32) (+SiLU) as a ResBlock runs the pair: the convolution also
+// writes the GroupNorm partial sums of its output (ConvGemmParams::gn_stats_out) and the GroupNorm makes no statistics pass.
+// h_dev: the convolution's output, y_dev: the GroupNorm's; AF_ERR_INVALID when the shape has no producer plan.
+int af_op_conv_gn(const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev,
+                  const float* gamma_dev, const float* beta_dev, float eps, int silu, float* h_dev, float* y_dev, int B,
+                  int Cin, int H, int W, int Cout, void* stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Tmp tmp;
+  if (Cin % 64 != 0 || Cout % 32 != 0) { af_set_error_msg("af_op_conv_gn: Cin%%64==0 and Cout%%32==0"); return AF_ERR_INVALID; }
+  const int HW = H * W, rows_pad = rup(Cout, 128), ldw = 9 * Cin;
+  OP_ALLOC(xn, (size_t)B * HW * Cin * 2, false);
+  OP_ALLOC(wn, (size_t)rows_pad * ldw * 2, true);
+  OP_ALLOC(hn, (size_t)B * HW * Cout * 2, true);
+  OP_ALLOC(yn, (size_t)B * HW * Cout * 2, false);
+  OP_ALLOC(ws, af_gn_workspace_bytes(B, HW), false);
+  OP_ALLOC(st, (size_t)B * (HW / 64 + 1) * 32 * 2 * sizeof(float), true);
+  void* rn = nullptr;
+  float* bn = nullptr;
+  OP_TRY(af_launch_nchw_to_nhwc<bf16>(x_dev, xn, B, Cin, HW, Cin, 1.f, s));
+  OP_TRY(af_launch_repack_weight<bf16>(w_dev, wn, Cout, Cin, Cin, 3, ldw, 0, 0, s));
+  if (bias_dev) {
+    bn = reinterpret_cast<float*>(tmp.get((size_t)rows_pad * 4, true));
+    if (!bn) return AF_ERR_HIP;
+    if (hipMemcpyAsync(bn, bias_dev, (size_t)Cout * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return AF_ERR_HIP;
+  }
+  if (residual_dev) {
+    rn = tmp.get((size_t)B * HW * Cout * 2, false);
+    if (!rn) return AF_ERR_HIP;
+    OP_TRY(af_launch_nchw_to_nhwc<bf16>(residual_dev, rn, B, Cout, HW, Cout, 1.f, s));
+  }
+  ConvGemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.src = xn; p.src_batch_stride = (long)HW * Cin; p.ldc = Cin; p.Cin = Cin;
+  p.Hs = H; p.Ws = W; p.Hi = H; p.Wi = W; p.Ho = H; p.Wo = W;
+  p.ks = 3; p.stride = 1; p.pad = 1;
+  p.W = wn; p.ldw = ldw; p.Wrows = rows_pad;
+  p.M = B * HW; p.N = Cout; p.K = ldw;
+  p.bias = bn; p.residual = rn; p.ldr = Cout; p.out = hn; p.ldo = Cout; p.alpha = 1.f;
+  p.k_logical = 9 * Cin;
+  const AfGemmPlan pl = af_plan_conv_gemm(p, 1, 2);
+  if (!af_conv_gn_stats_ok(p, pl, Cout / 32)) {
+    af_set_error_msg("af_op_conv_gn: no GroupNorm-statistics producer plan for M=%d N=%d K=%d", p.M, p.N, p.K);
+    return AF_ERR_INVALID;
+  }
+  p.gn_stats_out = reinterpret_cast<float*>(st);
+  p.gn_cpg = Cout / 32;
+  OP_TRY(af_launch_conv_gemm<bf16>(p, 1, s, &pl, nullptr));
+  OP_TRY(af_launch_groupnorm<bf16>(hn, (long)HW * Cout, Cout, B, HW, Cout, gamma_dev, beta_dev, eps, silu, yn, (long)HW * Cout,
+                                   Cout, ws, s, 0.f, reinterpret_cast<const float*>(st), HW / 64));
+  OP_TRY(af_launch_nhwc_to_nchw<bf16>(hn, h_dev, B, Cout, HW, Cout, s));
+  OP_TRY(af_launch_nhwc_to_nchw<bf16>(yn, y_dev, B, Cout, HW, Cout, s));
+  return 0;
+}
+
 int af_op_layernorm(int dtype, const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps,
                     float* y_dev, int64_t rows, int C, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

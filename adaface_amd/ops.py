@@ -115,6 +115,21 @@ def group_norm(x, weight, bias, eps=1e-5, silu=False, dtype="bf16"):
     return y
 
 
+def conv_gn(x, w, b, gamma, beta, eps=1e-5, silu=True, residual=None):
+    """conv3x3 (stride 1, bf16) then GroupNorm(32)(+SiLU) with the statistics summed in the convolution's epilogue
+    (af_op_conv_gn).  Returns (conv output, GroupNorm output)."""
+    lib = _lib.load()
+    x = _dev_f32(x)
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    h = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
+    y = torch.empty_like(h)
+    check(lib.af_op_conv_gn(ptr(x), ptr(_dev_f32(w)), ptr(_dev_f32(b)) if b is not None else None,
+                            ptr(_dev_f32(residual)) if residual is not None else None, ptr(_dev_f32(gamma)), ptr(_dev_f32(beta)),
+                            eps, 1 if silu else 0, ptr(h), ptr(y), B, Cin, H, W, Cout, stream_ptr()), "af_op_conv_gn")
+    return h, y
+
+
 def layer_norm(x, weight, bias, eps=1e-5, dtype="bf16"):
     lib = _lib.load()
     x = _dev_f32(x)

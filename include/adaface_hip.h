@@ -212,6 +212,11 @@ int af_op_conv2d(int dtype, const float* x_dev, const float* w_dev, const float*
 int af_op_linear(int dtype, const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev,
                  float* y_dev, int64_t M, int K, int N, int geglu, void* stream);
 /* F.group_norm(x, 32, gamma, beta, eps) on NCHW, optional SiLU. */
+/* conv3x3 (stride 1, bf16) + GroupNorm(32)(+SiLU) with the GroupNorm statistics summed in the convolution's epilogue, as the
+ * ResBlocks run the pair (openaimodel.py:259-279): h_dev = convolution output, y_dev = GroupNorm output, both fp32 NCHW */
+int af_op_conv_gn(const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev,
+                  const float* gamma_dev, const float* beta_dev, float eps, int silu, float* h_dev, float* y_dev, int B,
+                  int Cin, int H, int W, int Cout, void* stream);
 int af_op_groupnorm(int dtype, const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, int silu,
                     float* y_dev, int B, int C, int H, int W, void* stream);
 /* fp8 (OCP e4m3) operand variant of the UNet's ResBlock convolutions (BASELINE config 4: "fp8 MFMA QKV/conv"; the
@@ -223,6 +228,7 @@ int af_op_groupnorm(int dtype, const float* x_dev, const float* gamma_dev, const
 int af_set_fp8(af_handle* h, int on);
 int64_t af_fp8_gemm_launches(void); /* launches on the fp8 kernel since af_gemm_plan_counts_reset */
 int64_t af_halo8_launches(void);    /* launches of the eight-wave LDS-halo 3x3 kernel (also counted under tile 5) */
+int64_t af_gn_producer_launches(void); /* convolutions that also wrote the GroupNorm partial sums of their output (no statistics pass in the consumer) */
 int64_t af_up_phase4_launches(void); /* upsampled 3x3 convolutions run as four 2x2 phase convolutions on the stored map */
 int64_t af_rowpanel_launches(void); /* launches of the row-panel GEGLU kernel (K = 320, activations resident in registers) */
 int af_op_conv2d_fp8(const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev, float* y_dev,

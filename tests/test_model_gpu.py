@@ -315,6 +315,8 @@ def test_sd15_unet_batch_consistency(gpu, report):
             assert pc["ln_consumer"] == 30 and pc["ln_producer"] == 30, pc
             # the three Upsample convolutions as four 2x2 phase convolutions; row-panel GEMMs at the 64x64 and 32x32 levels
             assert pc["up_phase4"] == 3 and pc["rowpanel"] >= 35, pc
+            # ResBlock convolutions at the 64x64 / 32x32 levels that also summed the GroupNorm statistics of their output
+            assert pc["gn_producer"] >= 15, pc
             e = (eps16 - eps_f32).abs().max().item() / eps_f32.abs().max().item()
             report("sd15_unet Bf=16 bf16 forward vs f32-mode forward of the same batch", e, eps_f32.abs().max().item(), BATCH_TOL["bf16"])
             assert e <= BATCH_TOL["bf16"], e

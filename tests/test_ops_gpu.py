@@ -208,6 +208,38 @@ def test_conv2d_up_phase4(gpu, report, knobs, B, Cin, H, W, Cout, bias):
         assert torch.allclose(got.cpu()[sl], ref[sl], atol=2e-2 * scale, rtol=0)
 
 
+@pytest.mark.parametrize("B,Cin,C,H,W,res", [
+    (4, 320, 320, 64, 64, False),      # ResBlock conv1 at the 64x64 level: LDS-halo kernel, 10 channels per group
+    (16, 640, 640, 32, 32, True),      # conv2 + residual at 32x32: 20 channels per group
+    (16, 128, 1280, 16, 16, False),    # 40 channels per group (two groups per wave), 4 slabs per sample
+    (2, 64, 128, 64, 64, False),       # VAE width: the 256 x 128 tile, 4 channels per group
+    (1, 128, 512, 128, 128, True),     # 256 slabs per sample: more than the apply kernel folds -> gn_finalize_kernel
+])
+def test_conv_gn_producer_stats(gpu, report, knobs, B, Cin, C, H, W, res):
+    """GroupNorm statistics summed in the producer convolution's epilogue (ConvGemmParams::gn_stats_out): the GroupNorm of
+    the convolution's stored (bf16) output against torch.group_norm of that same tensor, and bit for bit the convolution
+    output against the launch without the statistics pass."""
+    from adaface_amd import _lib, ops
+    knobs("gemm_pp_minfill", 0)
+    g = torch.Generator().manual_seed(B + Cin + C + H)
+    x = _q(torch.randn(B, Cin, H, W, generator=g), "bf16")
+    w = _q(torch.randn(C, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin), "bf16")
+    b = torch.randn(C, generator=g) * 0.3
+    r = _q(torch.randn(B, C, H, W, generator=g), "bf16") if res else None
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    _lib.plan_counts(reset=True)
+    h, y = ops.conv_gn(x.to(gpu), w.to(gpu), b.to(gpu), gamma.to(gpu), beta.to(gpu), eps=1e-5, silu=True,
+                       residual=None if r is None else r.to(gpu))
+    assert _lib.plan_counts(reset=True)["gn_producer"] == 1
+    plain = ops.conv2d(x.to(gpu), w.to(gpu), b.to(gpu), residual=None if r is None else r.to(gpu), dtype="bf16")
+    assert _lib.plan_counts(reset=True)["gn_producer"] == 0
+    assert torch.equal(h, plain)
+    ref = F.silu(F.group_norm(h.cpu(), 32, gamma, beta, 1e-5))
+    _cmp(report, f"conv3x3+GN producer stats {Cin}->{C}@{H}x{W}", y, ref, "bf16")
+    ref2 = ops.group_norm(h, gamma.to(gpu), beta.to(gpu), eps=1e-5, silu=True, dtype="bf16")   # stand-alone statistics pass
+    assert (y - ref2).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("M,K,N,bias", [(32768, 320, 1280, True), (32868, 320, 640, False), (65536, 320, 1280, True),
                                         (16384, 640, 2560, True), (16434, 640, 192, False), (32768, 640, 2560, False)])
 def test_geglu_rowpanel(gpu, report, knobs, M, K, N, bias):
