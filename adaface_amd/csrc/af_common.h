@@ -84,7 +84,8 @@ struct AfKnobs {
   int ln_fuse;              // AF_LN_FUSE              0 = stand-alone LayerNorm kernels in front of the transformer GEMMs
   int geglu_rowpanel;       // AF_GEGLU_ROWPANEL       row-panel kernel (K = 320, >= 32768 rows): 0 = never, 1 = GEGLU only, 2 = the plain
                             //                         GEMMs of the 64x64-level transformers too, 3 = and its K = 640 form (GEGLU and
-                            //                         q / k / v of the 32x32 level, >= 16384 rows)
+                            //                         q / k / v of the 32x32 level, >= 16384 rows), 4 = and the K = 1280 form
+                            //                         ([>= 4096, 1280] -> 1280 of the 16x16 level)
   int conv_halo8;           // AF_CONV_HALO8           0 = 3x3 / stride-1 convs stay on the gathering eight-wave kernel (no LDS halo)
   int conv_fast_taps;       // AF_CONV_FAST_TAPS       0 = ping-pong convs recompute every tap's bounds check in the staging phase
   int pp_stagger;           // AF_PP_STAGGER           merged schedule: 1 = the two wave groups issue their LDS-DMA pieces behind alternate MFMAs

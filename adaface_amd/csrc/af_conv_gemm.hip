@@ -1626,7 +1626,8 @@ template <bool GEGLU, int KC_ = 5, int MJ_ = 2> struct RowPanelCfgT {
   static constexpr int LDS_BYTES = 3 * WBYTES + 8 * OBYTES;
   static constexpr int CPR = OCOLS / 8;            // 16-byte chunks per output row segment
   static constexpr int NST = WROWS * CPR / 64;     // 16-byte buffer stores per lane and column tile
-  static_assert(LDS_BYTES <= 160 * 1024 && (WROWS * CPR) % 64 == 0 && MJ * KC == 10, "row-panel LDS / store mapping / 80 fragment registers");
+  static_assert(LDS_BYTES <= 160 * 1024 && (WROWS * CPR) % 64 == 0 && (MJ * KC == 10 || (MJ == 1 && KC == 20)),
+                "row-panel LDS / store mapping / 80 (K = 1280, 16 rows per wave: 160) fragment registers");
 };
 typedef RowPanelCfgT<true> RowPanelCfg;
 
@@ -1915,6 +1916,11 @@ static int launch_rowpanel_one(const ConvGemmParams& p, hipStream_t stream) {
 static int launch_geglu_rowpanel(const ConvGemmParams& p, hipStream_t stream, bool k640 = false) {
   if (k640) return p.ln_stats ? launch_rowpanel_one<true, 1, false, 10, 1>(p, stream) : launch_rowpanel_one<true, 0, false, 10, 1>(p, stream);
   return p.ln_stats ? launch_rowpanel_one<true, 1, false>(p, stream) : launch_rowpanel_one<true, 0, false>(p, stream);
+}
+// K = 1280 (16x16 level, 4096 rows): 16 rows per wave x 1280 K = 160 fragment registers; N = 1280 only (eight column tiles
+// over eight workgroups per 128-row panel -- one tile of 20 steps each; longer N gains nothing over the tiled kernel)
+static int launch_plain_rowpanel_k1280(const ConvGemmParams& p, hipStream_t stream) {
+  return p.residual ? launch_rowpanel_one<false, 0, true, 20, 1>(p, stream) : launch_rowpanel_one<false, 0, false, 20, 1>(p, stream);
 }
 static int launch_plain_rowpanel(const ConvGemmParams& p, hipStream_t stream, bool k640 = false) {
   const bool res = p.residual != nullptr;
@@ -2801,6 +2807,12 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
         (!p.residual || p.ldr % 4 == 0)) {
       g_af_plan_counts[12] += 1;
       return launch_plain_rowpanel(p, stream);
+    }
+    if (g_af_knobs.geglu_rowpanel >= 4 && batch == 1 && p.ks == 1 && p.pad == 0 && p.stride == 1 && p.up == 0 && p.K == 1280 &&
+        p.Cin == 1280 && p.N == 1280 && p.splitk <= 1 && p.M >= 4096 && p.epilogue != AF_EPI_GEGLU && p.alpha == 1.0f &&
+        !p.rowbias && !p.ln_stats && !p.ln_stats_out && p.ldc >= p.Cin && (!p.residual || p.ldr % 4 == 0)) {
+      g_af_plan_counts[12] += 1;
+      return launch_plain_rowpanel_k1280(p, stream);
     }
     // K = 640 (32x32 level): GEGLU, and the q / k / v projection (N >= 1920: enough column tiles per workgroup)
     if (g_af_knobs.geglu_rowpanel >= 3 && batch == 1 && p.ks == 1 && p.pad == 0 && p.stride == 1 && p.up == 0 && p.K == 640 &&

@@ -267,13 +267,14 @@ def test_geglu_rowpanel(gpu, report, knobs, M, K, N, bias):
 
 
 @pytest.mark.parametrize("M,K,N,bias,res", [(32768, 320, 320, True, True), (32868, 320, 960, False, False), (65536, 320, 320, True, False),
-                                            (16384, 640, 1920, True, False), (16434, 640, 2400, False, False)])
+                                            (16384, 640, 1920, True, False), (16434, 640, 2400, False, False),
+                                            (4096, 1280, 1280, True, True), (4196, 1280, 1280, False, False)])
 def test_plain_rowpanel(gpu, report, knobs, M, K, N, bias, res):
     """The row-panel kernel on the non-GEGLU K = 320 GEMMs (160-column tiles, residual added in the accumulator layout) and
     on the K = 640 q / k / v projection (N >= 1920; 2400 = 15 tiles, an odd count that stays on one workgroup per panel):
     against torch and, bit for bit, against the tiled eight-wave kernel."""
     from adaface_amd import _lib, ops
-    knobs("geglu_rowpanel", 3)
+    knobs("geglu_rowpanel", 4)
     g = torch.Generator().manual_seed(M + N + 5)
     x = _q(torch.randn(M, K, generator=g), "bf16")
     w = _q(torch.randn(N, K, generator=g) / math.sqrt(K), "bf16")
