@@ -230,7 +230,7 @@ int64_t af_fp8_gemm_launches(void); /* launches on the fp8 kernel since af_gemm_
 int64_t af_halo8_launches(void);    /* launches of the eight-wave LDS-halo 3x3 kernel (also counted under tile 5) */
 int64_t af_gn_producer_launches(void); /* convolutions that also wrote the GroupNorm partial sums of their output (no statistics pass in the consumer) */
 int64_t af_up_phase4_launches(void); /* upsampled 3x3 convolutions run as four 2x2 phase convolutions on the stored map */
-int64_t af_rowpanel_launches(void); /* launches of the row-panel GEGLU kernel (K = 320, activations resident in registers) */
+int64_t af_rowpanel_launches(void); /* launches of the row-panel kernels (K = 320 / 640 / 1280 GEMMs with the activation rows resident in registers) */
 int af_op_conv2d_fp8(const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev, float* y_dev,
                      int B, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int upsample, int act_shift,
                      void* stream);
