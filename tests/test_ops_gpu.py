@@ -240,6 +240,20 @@ def test_conv_gn_producer_stats(gpu, report, knobs, B, Cin, C, H, W, res):
     assert (y - ref2).abs().max().item() <= 2e-2 * ref.abs().max().item()
 
 
+def test_conv_gn_producer_refuses_sliced_k(gpu):
+    """A convolution whose plan slices K (few output tiles: the slabs are summed by the reduce kernel, not by an epilogue
+    that sees whole outputs) has no statistics producer: the operator says so instead of writing partial sums of partial
+    sums, and the model keeps the stand-alone statistics pass for such layers (af_conv_gn_stats_ok)."""
+    from adaface_amd import ops
+    from adaface_amd._lib import AfError
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 1280, 8, 8, generator=g).to(gpu)
+    w = (torch.randn(1280, 1280, 3, 3, generator=g) / 100).to(gpu)
+    ones = torch.ones(1280, device=gpu)
+    with pytest.raises(AfError):
+        ops.conv_gn(x, w, None, ones, ones * 0)
+
+
 @pytest.mark.parametrize("M,K,N,bias", [(32768, 320, 1280, True), (32868, 320, 640, False), (65536, 320, 1280, True),
                                         (16384, 640, 2560, True), (16434, 640, 192, False), (32768, 640, 2560, False)])
 def test_geglu_rowpanel(gpu, report, knobs, M, K, N, bias):
