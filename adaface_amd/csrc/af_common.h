@@ -268,6 +268,10 @@ struct ConvGemmParams {
   float* ln_stats_out;
   const float* ln_stats;
   const float* ln_colsum;
+  // consumer on a ROW-PANEL kernel (a workgroup owns its rows for all of N): ln_parts_n > 0 -> ln_stats holds the producer's
+  // partial sums [ln_parts_n][M][2] and the kernel finalises (mu, rstd) of its rows itself: mu = sum * ln_inv_count, ...
+  int ln_parts_n;
+  float ln_inv_count, ln_eps;
   int k_tap_inner;        // ping-pong kernel (set by the launcher): K walked as (channel chunk, tap) instead of (tap, chunk)
   int pp_epilogue;        // ping-pong kernel (set by the launcher): 0 = direct for GEGLU / split-K slabs and LDS
                           // otherwise, 1 = always through LDS, 2 = always direct

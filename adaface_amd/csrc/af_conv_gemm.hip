@@ -1674,7 +1674,21 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
         xr[j][kc][u] = __builtin_bit_cast(pp_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xo, (kc * 64 + u * 32) * 2, 0));
     if constexpr (LNMODE == 1) {
       float2 st = float2{0.f, 0.f};
-      if (ok) st = *reinterpret_cast<const float2*>(p.ln_stats + (long)m * 2);
+      if (ok && p.ln_parts_n > 0) {
+        // un-finalised statistics: ln_stats = the producer's partial sums [parts][M][2]; this workgroup owns its rows for all
+        // of N, so it sums them itself (same order and arithmetic as ln_finalize_kernel) -- no finalize launch in between
+        float s1 = 0.f, s2 = 0.f;
+        for (int q = 0; q < p.ln_parts_n; ++q) {
+          const float2 pq2 = *reinterpret_cast<const float2*>(p.ln_stats + ((long)q * p.M + m) * 2);
+          s1 += pq2.x;
+          s2 += pq2.y;
+        }
+        const float mu = s1 * p.ln_inv_count;
+        const float var = fmaxf(s2 * p.ln_inv_count - mu * mu, 0.f);
+        st = float2{mu, __builtin_amdgcn_rsqf(var + p.ln_eps)};
+      } else if (ok) {
+        st = *reinterpret_cast<const float2*>(p.ln_stats + (long)m * 2);
+      }
       ln_mu[j] = st.x;
       ln_rs[j] = st.y;
     }
@@ -2717,6 +2731,29 @@ bool af_conv_gn_stats_ok(const ConvGemmParams& p, const AfGemmPlan& pl, int cpg)
          p.N == 32 * cpg && pow2(p.Ho * p.Wo) && p.Ho * p.Wo >= 64 && p.M % 64 == 0;
 }
 
+// Which row-panel kernel a bf16 launch with these (validated) parameters takes in ONE K slice: 0 none, 1 GEGLU K = 320,
+// 2 plain K = 320 (LayerNorm consumer / producer, residual), 3 plain K = 1280 -> 1280, 4 GEGLU K = 640, 5 plain K = 640
+// (N >= 1920).  The model asks before it decides who finalises LayerNorm statistics (ConvGemmParams::ln_parts_n).
+int af_conv_rowpanel_kind(const ConvGemmParams& p, int batch) {
+  const int lvl = g_af_knobs.geglu_rowpanel;
+  if (!lvl || batch != 1 || p.ks != 1 || p.pad != 0 || p.stride != 1 || p.up != 0 || p.splitk > 1 || p.rowbias || p.fp8 ||
+      p.Cin != p.K || p.ldc < p.Cin)
+    return 0;
+  const bool geglu = p.epilogue == AF_EPI_GEGLU;
+  if (p.K == RowPanelCfg::K && p.M >= 128 * RowPanelCfg::BM) {
+    if (geglu) return (p.N % RowPanelCfg::BN == 0 && !p.residual && !p.ln_stats_out) ? 1 : 0;
+    return (lvl >= 2 && p.N % 160 == 0 && p.alpha == 1.0f && !(p.ln_stats && p.ln_stats_out) && (!p.residual || p.ldr % 4 == 0)) ? 2 : 0;
+  }
+  if (p.K == 1280)
+    return (lvl >= 4 && p.N == 1280 && p.M >= 4096 && !geglu && p.alpha == 1.0f && !p.ln_stats && !p.ln_stats_out &&
+            (!p.residual || p.ldr % 4 == 0)) ? 3 : 0;
+  if (p.K == 640 && lvl >= 3 && p.M >= 16384 && !p.residual && !p.ln_stats_out) {
+    if (geglu) return p.N % 128 == 0 ? 4 : 0;
+    return (p.N % 160 == 0 && p.N >= 1920 && p.alpha == 1.0f) ? 5 : 0;
+  }
+  return 0;
+}
+
 template <typename T>
 int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t stream, const AfGemmPlan* plan, void* ws) {
   constexpr int BK = 128 / sizeof(T);
@@ -2792,39 +2829,21 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
     af_set_error_msg("conv_gemm: LayerNorm-fused launch planned on a kernel without that epilogue (tile %d)", pl.tile);
     return -1;
   }
-  // GEGLU over K = 320 with enough rows for one workgroup per CU: the row-panel kernel (activations in registers)
+  // the row-panel kernels (activation rows resident in registers): K = 320 / 640 / 1280 GEMMs with enough rows
   if constexpr (sizeof(T) == 2) {
-    if (p.epilogue == AF_EPI_GEGLU && g_af_knobs.geglu_rowpanel && batch == 1 && p.ks == 1 && p.pad == 0 && p.stride == 1 &&
-        p.up == 0 && p.K == RowPanelCfg::K && p.Cin == RowPanelCfg::K && p.N % RowPanelCfg::BN == 0 && p.splitk <= 1 &&
-        p.M >= 128 * RowPanelCfg::BM && !p.residual && !p.rowbias && !p.ln_stats_out && p.ldc >= p.Cin) {
-      g_af_plan_counts[12] += 1;
-      return launch_geglu_rowpanel(p, stream);
+    const int rk = af_conv_rowpanel_kind(p, batch);
+    if (p.ln_parts_n > 0 && !rk) {
+      af_set_error_msg("conv_gemm: un-finalised LayerNorm statistics handed to a launch that is not a row-panel one");
+      return -1;
     }
-    // ... and the other K = 320 GEMMs of those transformers (N = 320 / 960), LayerNorm-consumer / -producer epilogue, residual
-    if (p.epilogue != AF_EPI_GEGLU && g_af_knobs.geglu_rowpanel >= 2 && batch == 1 && p.ks == 1 && p.pad == 0 && p.stride == 1 &&
-        p.up == 0 && p.K == RowPanelCfg::K && p.Cin == RowPanelCfg::K && p.N % 160 == 0 && p.splitk <= 1 && p.alpha == 1.0f &&
-        p.M >= 128 * RowPanelCfg::BM && !p.rowbias && !(p.ln_stats && p.ln_stats_out) && p.ldc >= p.Cin &&
-        (!p.residual || p.ldr % 4 == 0)) {
-      g_af_plan_counts[12] += 1;
-      return launch_plain_rowpanel(p, stream);
-    }
-    if (g_af_knobs.geglu_rowpanel >= 4 && batch == 1 && p.ks == 1 && p.pad == 0 && p.stride == 1 && p.up == 0 && p.K == 1280 &&
-        p.Cin == 1280 && p.N == 1280 && p.splitk <= 1 && p.M >= 4096 && p.epilogue != AF_EPI_GEGLU && p.alpha == 1.0f &&
-        !p.rowbias && !p.ln_stats && !p.ln_stats_out && p.ldc >= p.Cin && (!p.residual || p.ldr % 4 == 0)) {
-      g_af_plan_counts[12] += 1;
-      return launch_plain_rowpanel_k1280(p, stream);
-    }
-    // K = 640 (32x32 level): GEGLU, and the q / k / v projection (N >= 1920: enough column tiles per workgroup)
-    if (g_af_knobs.geglu_rowpanel >= 3 && batch == 1 && p.ks == 1 && p.pad == 0 && p.stride == 1 && p.up == 0 && p.K == 640 &&
-        p.Cin == 640 && p.splitk <= 1 && p.M >= 16384 && !p.residual && !p.rowbias && !p.ln_stats_out && p.ldc >= p.Cin) {
-      if (p.epilogue == AF_EPI_GEGLU && p.N % 128 == 0) {
-        g_af_plan_counts[12] += 1;
-        return launch_geglu_rowpanel(p, stream, true);
-      }
-      if (p.epilogue != AF_EPI_GEGLU && p.N % 160 == 0 && p.N >= 1920 && p.alpha == 1.0f) {
-        g_af_plan_counts[12] += 1;
-        return launch_plain_rowpanel(p, stream, true);
-      }
+    if (rk) g_af_plan_counts[12] += 1;
+    switch (rk) {
+      case 1: return launch_geglu_rowpanel(p, stream);
+      case 2: return launch_plain_rowpanel(p, stream);
+      case 3: return launch_plain_rowpanel_k1280(p, stream);
+      case 4: return launch_geglu_rowpanel(p, stream, true);
+      case 5: return launch_plain_rowpanel(p, stream, true);
+      default: break;
     }
   }
   if (pl.halo_tw == 256) {

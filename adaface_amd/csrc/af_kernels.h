@@ -16,6 +16,7 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
                         const float* pre_partial = nullptr, int pre_npart = 0);   // statistics already summed by the producer
 // would a bf16 convolution with these parameters on this plan write GroupNorm partial sums (ConvGemmParams::gn_stats_out)?
 bool af_conv_gn_stats_ok(const ConvGemmParams& p, const AfGemmPlan& pl, int cpg);
+int af_conv_rowpanel_kind(const ConvGemmParams& p, int batch);   // 0 = not a row-panel launch (p.splitk as planned)
 template <typename T>
 int af_launch_layernorm(const void* x, int ldx, long rows, int Cn, const float* gamma, const float* beta,
                         float eps, void* y, int ldy, hipStream_t stream, float fp8_mul = 0.f);

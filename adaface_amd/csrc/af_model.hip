@@ -778,6 +778,12 @@ struct Runner {
   struct LnArgs {
     const float* stats = nullptr; const float* colsum = nullptr;   // consumer: finalised (mu, rstd) per row, column sums
     float* stats_out = nullptr;                                    // producer: partial sums [parts][M][2]
+    // consumer, statistics not finalised yet: the producer's partial sums for exactly this launch's rows.  A row-panel
+    // launch sums them in its prologue; any other gets an ln_finalize launch into `stats_buf` first (conv() decides)
+    const float* parts_in = nullptr;
+    int parts_n = 0, count = 0;
+    float eps = 0.f;
+    float* stats_buf = nullptr;
   };
   int ln_finalize(const float* part, int parts, long M, int count, float eps, float* out) {
     if (dry) return 0;
@@ -842,9 +848,14 @@ struct Runner {
     out.gn_part = nullptr; out.gn_npart = 0;
     ConvGemmParams p;
     conv_params(p, L, x, out, stride, up, residual, rowbias, ldrb, n_valid, pad);
+    bool ln_parts_pending = false;
     if (ln) {
       p.ln_stats = ln->stats; p.ln_colsum = ln->colsum;
       p.ln_stats_out = ln->stats_out;
+      if (ln->parts_in) {            // (resolved below, once the plan is known)
+        p.ln_stats = ln->stats_buf;
+        ln_parts_pending = true;
+      }
     }
     if (x.C < L.cin || x.ld < L.cin_pad) {
       af_set_error_msg("conv: input has %d channels (ld %d), layer expects %d (padded %d)", x.C, x.ld, L.cin, L.cin_pad);
@@ -853,6 +864,18 @@ struct Runner {
     if (x.f8 && (!L.w8 || ln)) { af_set_error_msg("conv: e4m3 input without an fp8 weight twin"); return AF_ERR_STATE; }
     const AfGemmPlan pl = af_plan_conv_gemm(p, 1, (int)esize(dt));
     if (x.f8 && pl.tile < 4) { af_set_error_msg("conv: e4m3 input on a shape without an fp8 plan"); return AF_ERR_STATE; }
+    if (ln_parts_pending) {
+      ConvGemmParams q = p;
+      q.splitk = pl.splitk;
+      if (dt == AF_DTYPE_BF16 && af_conv_rowpanel_kind(q, 1)) {
+        p.ln_stats = ln->parts_in;
+        p.ln_parts_n = ln->parts_n;
+        p.ln_inv_count = 1.0f / (float)ln->count;
+        p.ln_eps = ln->eps;
+      } else {
+        AF_TRY(ln_finalize(ln->parts_in, ln->parts_n, (long)p.M, ln->count, ln->eps, ln->stats_buf));
+      }
+    }
     if (want_gn && dt == AF_DTYPE_BF16 && out.C % 32 == 0 && out.C == p.N && af_conv_gn_stats_ok(p, pl, out.C / 32)) {
       const int npart = out.H * out.W / 64;
       const size_t bytes = (size_t)out.B * npart * 32 * 2 * sizeof(float);
@@ -1010,10 +1033,18 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out, bool twin
   if (ln_parts && !st_row) { af_set_error_msg("arena exhausted (LayerNorm statistics)"); return AF_ERR_STATE; }
   float *st_t = st_part, *st_1 = st_part, *st_2 = st_part;   // one tensor's statistics are live at a time
   auto producer = [&](float* st) { Runner::LnArgs a; a.stats_out = st; return a; };
+  // consumer of statistics that conv() finalises (or lets a row-panel kernel finalise) itself ...
   auto consumer = [&](const float* st, const float* cs, const Norm& ln) {
     Runner::LnArgs a; a.colsum = cs;
+    a.parts_in = st; a.parts_n = ln_parts; a.count = C; a.eps = ln.eps;
+    a.stats_buf = st_row;
+    return a;
+  };
+  // ... and of statistics already finalised into st_row (the twin block's cross-attention query: finalised for half the rows,
+  // copied for the other half)
+  auto consumer_final = [&](const float* cs) {
+    Runner::LnArgs a; a.colsum = cs;
     a.stats = st_row;
-    (void)st; (void)ln;
     return a;
   };
   // (rows: the statistics of a half-batch producer are laid out for ITS row count)
@@ -1043,7 +1074,6 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out, bool twin
         AF_TRY(R.layernorm(blk.ln1, tp, n8));
         AF_TRY(R.conv(blk.qkv1, n8, qkvp, 1, 0, nullptr, nullptr, 0));
       } else if (ln_parts) {
-        AF_TRY(finalize(st_t, blk.ln1, (long)Bp * N));
         const Runner::LnArgs ca = consumer(st_t, blk.qkv1_cs, blk.ln1);
         AF_TRY(R.conv(blk.qkv1_ln, tp, qkvp, 1, 0, nullptr, nullptr, 0, -1, -1, &ca));
       } else {
@@ -1072,10 +1102,13 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out, bool twin
     // --- x = x + attn2(norm2(x), context) ---
     Act q = R.alloc_act(B, H, W, C);
     if (ln_parts) {
-      AF_TRY(finalize(st_1, blk.ln2, (long)Bp * N));
-      if (pre && !R.dry)   // (mu, rstd) of the first half's rows serve the second half as well
-        HIP_CHECK_RET(hipMemcpyAsync(st_row + (size_t)Bh * N * 2, st_row, (size_t)Bh * N * 2 * sizeof(float), hipMemcpyDeviceToDevice, R.s));
-      const Runner::LnArgs ca = consumer(st_1, blk.q2_cs, blk.ln2);
+      Runner::LnArgs ca = consumer(st_1, blk.q2_cs, blk.ln2);
+      if (pre) {   // the producer ran on the first half: finalise its rows, (mu, rstd) serve the second half as well
+        AF_TRY(finalize(st_1, blk.ln2, (long)Bh * N));
+        if (!R.dry)
+          HIP_CHECK_RET(hipMemcpyAsync(st_row + (size_t)Bh * N * 2, st_row, (size_t)Bh * N * 2 * sizeof(float), hipMemcpyDeviceToDevice, R.s));
+        ca = consumer_final(blk.q2_cs);
+      }
       AF_TRY(R.conv(blk.q2_ln, t1, q, 1, 0, nullptr, nullptr, 0, -1, -1, &ca));
     } else {
       AF_TRY(R.layernorm(blk.ln2, t1, n));
@@ -1135,7 +1168,6 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out, bool twin
     // --- x = ff(norm3(x)) + x ---
     Act f = R.alloc_act(B, H, W, 4 * C);
     if (ln_parts) {
-      AF_TRY(finalize(st_2, blk.ln3, (long)B * N));
       const Runner::LnArgs ca = consumer(st_2, blk.ff1_cs, blk.ln3);
       AF_TRY(R.conv(blk.ff1_ln, t2, f, 1, 0, nullptr, nullptr, 0, 8 * C, -1, &ca));
     } else {
