@@ -104,6 +104,8 @@ _SIGS = [
     ("af_clip_text_forward", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P]),
     ("af_clip_text_forward3", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P, _P]),
     ("af_op_timestep_embedding", C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P]),
+    ("af_flops_issued", C.c_double, [C.c_int]),
+    ("af_clock_probe", C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGS]
 

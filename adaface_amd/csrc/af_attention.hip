@@ -492,8 +492,10 @@ template <bool RUNMAX> __device__ __forceinline__ bool pass(const AttnParams& p,
     for (int j = 0; j < PPW; ++j) {
       const int piece = wave + WAVES * j;
       if (piece >= NPIECE) continue;
-      if (piece < KP) { if (act[j]) lds_dma16(rs_k, base + piece * 1024, voff[j], (unsigned)(t0 * p.ldk * 2)); }
-      else { if (act[j]) lds_dma16(rs_v, base + K_BYTES + (piece - KP) * 1024, voff[j], (unsigned)(t0 * p.ldv * 2)); }
+      // the tile base travels in the per-lane VECTOR offset: the buffer range check that zero-fills rows >= Nk of the
+      // last tile is documented for voffset + instruction offset only, not for soffset
+      if (piece < KP) { if (act[j]) lds_dma16(rs_k, base + piece * 1024, voff[j] + (unsigned)(t0 * p.ldk * 2), 0u); }
+      else { if (act[j]) lds_dma16(rs_v, base + K_BYTES + (piece - KP) * 1024, voff[j] + (unsigned)(t0 * p.ldv * 2), 0u); }
     }
   };
   const int nt = (p.Nk + 63) / 64;

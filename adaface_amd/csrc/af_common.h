@@ -46,12 +46,16 @@ enum { AF_K_CONV_GEMM = 0, AF_K_ATTENTION = 1, AF_K_GROUPNORM = 2, AF_K_LAYERNOR
 extern int g_af_prof_enabled;
 extern int g_af_prof_stride;              // bracket only every stride-th launch of a class (>= 1)
 extern long g_af_prof_seen[AF_K_COUNT];   // launches seen per class since af_prof_reset
+extern double g_af_flops_issued;          // FLOPs handed to GEMM / conv / attention launches since af_flops_issued(reset): what the
+                                          // path EXECUTES (phase-decomposed upsamplers and the shared CFG prefix spend fewer
+                                          // than the reference's algorithm; bench.py reports both fractions)
 void af_prof_begin_impl(int cls, hipStream_t s, double flops, double bytes);
 void af_prof_end_impl(hipStream_t s);
 struct AfProfScope {
   hipStream_t s;
   bool on;
   AfProfScope(int cls, hipStream_t s_, double flops, double bytes) : s(s_), on(((g_af_prof_enabled >> cls) & 1) != 0) {
+    g_af_flops_issued += flops;
     // an event pair costs ~9 us of stream time on MI355X (measured: bracketing every GEMM and attention launch slowed
     // the 50-step batch by 10 %), so the bench samples every stride-th launch of a class instead of all of them
     if (on) on = (g_af_prof_seen[cls]++ % g_af_prof_stride) == 0;

@@ -56,24 +56,29 @@ __global__ void gather_rows_cast_kernel(const float* __restrict__ x, const int* 
   }
 }
 
-// ---- subject-token convolutional attention (ldm/util.py:701-879 replace_rows_by_conv_attn, 3x3) ----
-// Step 1: pointwise scores of the nine subject keys: s9[bb][h][p][t] = scale * q[b][p][h] . k[b][S-9+t][h]
-// (the subject tokens sit at the END of the cached key list: set_context permutes them there).
-template <typename T>
+// ---- subject-token convolutional attention (ldm/util.py:701-879 replace_rows_by_conv_attn; kernel sizes 2, 3, 4) ----
+// KS x KS taps, NT = KS^2 subject tokens in tap order (row-major).  The reference pads q by (left, right, top, bottom) =
+// (0,1,0,1) / (1,1,1,1) / (1,2,1,2) for KS = 2 / 3 / 4 (util.py:747-760): tap (ty, tx) reads pixel (y + ty - P0, x + tx - P0)
+// with P0 = the left / top pad, and subject token j = (jy, jx) receives the conv map shifted by (dy, dx) = (jy - P0, jx - P0)
+// with zero fill (util.py:812-836): column_j(y, x) = A(y - dy, x - dx).
+// Step 1: pointwise scores of the NT subject keys: sN[bb][h][p][t] = scale * q[b][p][h] . k[b][tok0+t][h]
+// (the subject tokens sit at the END of the cached key list: set_context permutes them there; tok0 = their first row).
+template <typename T, int KS>
 __global__ __launch_bounds__(256) void subj_scores_kernel(const T* __restrict__ q, int ldq, long bsq,
-                                                          const T* __restrict__ kv, int ldk, long bsk, int S,
-                                                          float* __restrict__ s9, int N, int H, int dh, float scale) {
-  __shared__ float ks[9 * 160];
+                                                          const T* __restrict__ kv, int ldk, long bsk, int tok0,
+                                                          float* __restrict__ sN, int N, int H, int dh, float scale) {
+  constexpr int NT = KS * KS;
+  __shared__ float ks[NT * 160];
   const int h = blockIdx.y, b = blockIdx.z;
-  for (int i = threadIdx.x; i < 9 * dh; i += 256)
-    ks[i] = to_f32<T>(kv[(long)b * bsk + (long)(S - 9 + i / dh) * ldk + h * dh + (i % dh)]);
+  for (int i = threadIdx.x; i < NT * dh; i += 256)
+    ks[i] = to_f32<T>(kv[(long)b * bsk + (long)(tok0 + i / dh) * ldk + h * dh + (i % dh)]);
   __syncthreads();
   const int pp = blockIdx.x * 256 + threadIdx.x;
   if (pp >= N) return;
   const T* qp = q + (long)b * bsq + (long)pp * ldq + h * dh;
-  float acc[9];
+  float acc[NT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  for (int t = 0; t < NT; ++t) acc[t] = 0.f;
   for (int c = 0; c < dh; c += 4) {
     Quad<T> qv;
     qv.load(qp + c);
@@ -81,43 +86,45 @@ __global__ __launch_bounds__(256) void subj_scores_kernel(const T* __restrict__ 
     for (int e = 0; e < 4; ++e) {
       const float f = to_f32<T>(qv.e[e]);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) acc[t] = fmaf(f, ks[t * dh + c + e], acc[t]);
+      for (int t = 0; t < NT; ++t) acc[t] = fmaf(f, ks[t * dh + c + e], acc[t]);
     }
   }
-  float* o = s9 + (((long)b * H + h) * N + pp) * 9;
+  float* o = sN + (((long)b * H + h) * N + pp) * NT;
 #pragma unroll
-  for (int t = 0; t < 9; ++t) o[t] = acc[t] * scale;
+  for (int t = 0; t < NT; ++t) o[t] = acc[t] * scale;
 }
 
-// Step 2: conv scores A(y,x) = ks^-1.5 * sum_t s9[(y+ty-1, x+tx-1)][t] (zero outside the map), column j of the subject
-// = A shifted by (dy,dx) = (j/3-1, j%3-1) with zero fill, then the exact softmax merge of the nine replaced keys with
-// the flash result over the other S-9 keys:  out = (w_U O_U + sum_j e_j v_j) / (w_U + sum_j e_j),
-// w_U = 2^(lse_U - M), e_j = 2^(r_j log2e - M).  o holds O_U on entry and the merged output on exit.
-template <typename T>
-__global__ __launch_bounds__(256) void conv_attn_merge_kernel(const float* __restrict__ s9, const float* __restrict__ lse,
-                                                              const T* __restrict__ kv, int ldk, long bsk, int S,
+// Step 2: conv scores A(y,x) = KS^-1.5 * sum_t sN[(y+ty-P0, x+tx-P0)][t] (zero outside the map), column j of the subject
+// = A shifted by (dy,dx) = (j/KS-P0, j%KS-P0) with zero fill, then the exact softmax merge of the NT replaced keys with
+// the flash result over the other S-NT keys:  out = (w_U O_U + sum_j e_j v_j) / (w_U + sum_j e_j),
+// w_U = 2^(lse_U - M), e_j = 2^(r_j log2e - M).  o holds O_U on entry and the merged output on exit, lse likewise (a sample
+// that carries several subject strings -- attention.py:208-216 loops over them -- merges them one after the other).
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void conv_attn_merge_kernel(const float* __restrict__ sN, float* __restrict__ lse,
+                                                              const T* __restrict__ kv, int ldk, long bsk, int tok0,
                                                               T* __restrict__ o, int ldo, long bso, int N, int H, int dh,
                                                               int Hh, int Ww) {
-  __shared__ float vs[9 * 160];
+  constexpr int NT = KS * KS, P0 = KS == 2 ? 0 : 1;
+  __shared__ float vs[NT * 160];
   const int h = blockIdx.y, b = blockIdx.z;
-  for (int i = threadIdx.x; i < 9 * dh; i += 256)
-    vs[i] = to_f32<T>(kv[(long)b * bsk + (long)(S - 9 + i / dh) * ldk + H * dh + h * dh + (i % dh)]);   // V half
+  for (int i = threadIdx.x; i < NT * dh; i += 256)
+    vs[i] = to_f32<T>(kv[(long)b * bsk + (long)(tok0 + i / dh) * ldk + H * dh + h * dh + (i % dh)]);   // V half
   __syncthreads();
   const int pp = blockIdx.x * 256 + threadIdx.x;
   if (pp >= N) return;
   const int y = pp / Ww, x = pp - y * Ww;
-  const float* sb = s9 + ((long)b * H + h) * N * 9;
-  const float inv_norm = 0.19245008972987526f;   // 3^-1.5
-  float r[9];
+  const float* sb = sN + ((long)b * H + h) * N * NT;
+  const float inv_norm = KS == 2 ? 0.35355339059327373f : (KS == 3 ? 0.19245008972987526f : 0.125f);   // KS^-1.5
+  float r[NT];
 #pragma unroll
-  for (int j = 0; j < 9; ++j) {
-    const int yy = y - (j / 3 - 1), xx = x - (j % 3 - 1);
+  for (int j = 0; j < NT; ++j) {
+    const int yy = y - (j / KS - P0), xx = x - (j % KS - P0);
     float a = 0.f;
     if ((unsigned)yy < (unsigned)Hh && (unsigned)xx < (unsigned)Ww) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
-        if ((unsigned)y2 < (unsigned)Hh && (unsigned)x2 < (unsigned)Ww) a += sb[(long)(y2 * Ww + x2) * 9 + t];
+      for (int t = 0; t < NT; ++t) {
+        const int y2 = yy + t / KS - P0, x2 = xx + t % KS - P0;
+        if ((unsigned)y2 < (unsigned)Hh && (unsigned)x2 < (unsigned)Ww) a += sb[(long)(y2 * Ww + x2) * NT + t];
       }
     }
     r[j] = a * inv_norm * 1.44269504088896340736f;   // to the log2 domain of the flash kernel
@@ -125,12 +132,13 @@ __global__ __launch_bounds__(256) void conv_attn_merge_kernel(const float* __res
   const float L = lse[((long)b * H + h) * N + pp];
   float M = L;
 #pragma unroll
-  for (int j = 0; j < 9; ++j) M = fmaxf(M, r[j]);
+  for (int j = 0; j < NT; ++j) M = fmaxf(M, r[j]);
   const float wU = exp2f(L - M);
   float den = wU;
 #pragma unroll
-  for (int j = 0; j < 9; ++j) { r[j] = exp2f(r[j] - M); den += r[j]; }
+  for (int j = 0; j < NT; ++j) { r[j] = exp2f(r[j] - M); den += r[j]; }
   const float inv = 1.0f / den;
+  lse[((long)b * H + h) * N + pp] = M + log2f(den);   // log-sum-exp including these NT keys: the next subject string merges onto it
   T* op = o + (long)b * bso + (long)pp * ldo + h * dh;
   for (int c = 0; c < dh; c += 4) {
     Quad<T> ov;
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_attn_merge_kernel(const float* __res
     for (int e = 0; e < 4; ++e) {
       float v = wU * to_f32<T>(ov.e[e]);
 #pragma unroll
-      for (int j = 0; j < 9; ++j) v = fmaf(r[j], vs[j * dh + c + e], v);
+      for (int j = 0; j < NT; ++j) v = fmaf(r[j], vs[j * dh + c + e], v);
       ov.e[e] = from_f32<T>(v * inv);
     }
     ov.store(op + c);
@@ -400,18 +408,29 @@ int af_launch_gather_rows_cast(const float* x, const int* rowmap, void* y, long 
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-template <typename T>
-int af_launch_conv_attn(const void* q, int ldq, long bsq, const void* kv, int ldk, long bsk, int S, float* s9,
-                        const float* lse, void* o, int ldo, long bso, int B, int N, int H, int dh, int Hh, int Ww,
-                        float scale, hipStream_t s) {
-  if (dh > 160 || dh % 4 != 0 || Hh * Ww != N) return -1;
+template <typename T, int KS>
+static int launch_conv_attn_ks(const void* q, int ldq, long bsq, const void* kv, int ldk, long bsk, int tok0, float* sN,
+                               float* lse, void* o, int ldo, long bso, int B, int N, int H, int dh, int Hh, int Ww,
+                               float scale, hipStream_t s) {
   dim3 grid((N + 255) / 256, H, B);
-  hipLaunchKernelGGL((subj_scores_kernel<T>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(q), ldq, bsq,
-                     reinterpret_cast<const T*>(kv), ldk, bsk, S, s9, N, H, dh, scale);
-  hipLaunchKernelGGL((conv_attn_merge_kernel<T>), grid, dim3(256), 0, s, s9, lse, reinterpret_cast<const T*>(kv), ldk, bsk,
-                     S, reinterpret_cast<T*>(o), ldo, bso, N, H, dh, Hh, Ww);
+  hipLaunchKernelGGL((subj_scores_kernel<T, KS>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(q), ldq, bsq,
+                     reinterpret_cast<const T*>(kv), ldk, bsk, tok0, sN, N, H, dh, scale);
+  hipLaunchKernelGGL((conv_attn_merge_kernel<T, KS>), grid, dim3(256), 0, s, sN, lse, reinterpret_cast<const T*>(kv), ldk, bsk,
+                     tok0, reinterpret_cast<T*>(o), ldo, bso, N, H, dh, Hh, Ww);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
+}
+template <typename T>
+int af_launch_conv_attn(const void* q, int ldq, long bsq, const void* kv, int ldk, long bsk, int tok0, float* sN,
+                        float* lse, void* o, int ldo, long bso, int B, int N, int H, int dh, int Hh, int Ww,
+                        float scale, int ks, hipStream_t s) {
+  if (dh > 160 || dh % 4 != 0 || Hh * Ww != N || tok0 <= 0) return -1;
+  switch (ks) {
+    case 2: return launch_conv_attn_ks<T, 2>(q, ldq, bsq, kv, ldk, bsk, tok0, sN, lse, o, ldo, bso, B, N, H, dh, Hh, Ww, scale, s);
+    case 3: return launch_conv_attn_ks<T, 3>(q, ldq, bsq, kv, ldk, bsk, tok0, sN, lse, o, ldo, bso, B, N, H, dh, Hh, Ww, scale, s);
+    case 4: return launch_conv_attn_ks<T, 4>(q, ldq, bsq, kv, ldk, bsk, tok0, sN, lse, o, ldo, bso, B, N, H, dh, Hh, Ww, scale, s);
+    default: return -1;
+  }
 }
 template <typename T> int af_launch_cast_to_f32(const void* x, float* y, long n, hipStream_t s) {
   hipLaunchKernelGGL((cast_to_f32_kernel<T>), EW_GRID(n), dim3(256), 0, s, reinterpret_cast<const T*>(x), y, n);
@@ -522,8 +541,8 @@ int af_launch_nchw_to_uint8(const float* x, uint8_t* y, int B, int HW, hipStream
   template int af_launch_nhwc_to_nchw<T>(const void*, float*, int, int, int, int, hipStream_t);               \
   template int af_launch_cast_f32<T>(const float*, void*, long, hipStream_t);                                 \
   template int af_launch_gather_rows_cast<T>(const float*, const int*, void*, long, int, hipStream_t);         \
-  template int af_launch_conv_attn<T>(const void*, int, long, const void*, int, long, int, float*, const float*, \
-                                      void*, int, long, int, int, int, int, int, int, float, hipStream_t);    \
+  template int af_launch_conv_attn<T>(const void*, int, long, const void*, int, long, int, float*, float*, \
+                                      void*, int, long, int, int, int, int, int, int, float, int, hipStream_t); \
   template int af_launch_cast_to_f32<T>(const void*, float*, long, hipStream_t);                              \
   template int af_launch_timestep_embedding<T>(const long long*, void*, int, int, hipStream_t);               \
   template int af_launch_silu<T>(const void*, void*, long, hipStream_t);                                      \

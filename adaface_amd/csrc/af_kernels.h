@@ -28,13 +28,14 @@ template <typename T> int af_launch_cast_f32(const float* x, void* y, long n, hi
 // fp32 [rows][D] -> T with dst row r taken from src row rowmap[r]
 template <typename T>
 int af_launch_gather_rows_cast(const float* x, const int* rowmap, void* y, long rows, int D, hipStream_t s);
-// subject-token 3x3 conv attention (ldm/util.py:701-879) for B samples whose nine subject keys are rows S-9..S-1 of
-// kv [S][2*H*dh] (K | V): o holds the flash result over the first S-9 keys (its log2-domain log-sum-exp in lse
-// [B][H][N]) and is overwritten by the merged attention output; s9 = scratch [B][H][N][9] floats
+// subject-token ks x ks conv attention (ldm/util.py:701-879; ks = 2, 3, 4) for B samples whose ks^2 subject keys are rows
+// tok0..tok0+ks^2-1 of kv [S][2*H*dh] (K | V): o holds the flash result over the keys in front of the subject tokens (its
+// log2-domain log-sum-exp in lse [B][H][N]) and is overwritten by the merged attention output, lse by the merged
+// log-sum-exp (several subject strings per sample merge one after the other); sN = scratch [B][H][N][ks^2] floats
 template <typename T>
-int af_launch_conv_attn(const void* q, int ldq, long bsq, const void* kv, int ldk, long bsk, int S, float* s9,
-                        const float* lse, void* o, int ldo, long bso, int B, int N, int H, int dh, int Hh, int Ww,
-                        float scale, hipStream_t s);
+int af_launch_conv_attn(const void* q, int ldq, long bsq, const void* kv, int ldk, long bsk, int tok0, float* sN,
+                        float* lse, void* o, int ldo, long bso, int B, int N, int H, int dh, int Hh, int Ww,
+                        float scale, int ks, hipStream_t s);
 template <typename T> int af_launch_cast_to_f32(const void* x, float* y, long n, hipStream_t s);
 template <typename T> int af_launch_timestep_embedding(const long long* t, void* y, int B, int dim, hipStream_t s);
 template <typename T> int af_launch_silu(const void* x, void* y, long n, hipStream_t s);

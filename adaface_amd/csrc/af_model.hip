@@ -76,6 +76,7 @@ static int* knob_slot(const char* name) {
 int g_af_prof_enabled = 0;
 int g_af_prof_stride = 1;
 long g_af_prof_seen[AF_K_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+double g_af_flops_issued = 0.0;
 namespace {
 struct ProfRec {
   hipEvent_t start, stop;
@@ -1122,39 +1123,42 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out, bool twin
     }
     const int ca_layer = (w.ca_slot + (int)d) / (int)w.blocks.size();
     // subject-token conv attention: every conditioned layer except CA layers 6-10 (openaimodel.py:922-932)
-    const bool conv_attn = h->conv_ks == 3 && !h->conv_batch.empty() && !(ca_layer >= 6 && ca_layer <= 10);
+    const bool conv_attn = h->conv_ks >= 2 && !h->conv_batch.empty() && !(ca_layer >= 6 && ca_layer <= 10);
     if (!conv_attn) {
       AF_TRY(R.attention(q.p, C, (long)N * C, kv.kv, 2 * C, (long)S * 2 * C, R.dry ? nullptr : R.elem_ptr(kv.kv, C),
                          2 * C, (long)S * 2 * C, a, N, S, w.heads, w.dh));
     } else {
       // runs of consecutive samples with / without the subject: flash attention over all S keys, or over the first
-      // S-9 (the subject's keys were moved to the end by af_set_context) followed by the exact softmax merge with
-      // the nine convolutional score columns (af_launch_conv_attn)
+      // S-ks^2 (the subject's keys were moved to the end by af_set_context) followed by the exact softmax merge with
+      // the ks^2 convolutional score columns (af_launch_conv_attn)
       const size_t mk3 = R.A.mark();
+      const int nt = h->conv_ks * h->conv_ks;
       float* lse = reinterpret_cast<float*>(R.A.alloc((size_t)B * w.heads * N * sizeof(float)));
-      float* s9 = reinterpret_cast<float*>(R.A.alloc((size_t)B * w.heads * N * 9 * sizeof(float)));
+      float* s9 = reinterpret_cast<float*>(R.A.alloc((size_t)B * w.heads * N * nt * sizeof(float)));
       if (!lse || !s9) { af_set_error_msg("arena exhausted (conv attention scratch)"); return AF_ERR_STATE; }
       void* vptr = R.dry ? nullptr : R.elem_ptr(kv.kv, C);
+      // runs of consecutive samples that carry the same NUMBER of subject strings (0 = plain attention over all S keys)
+      auto groups = [&](int b) { return (int)std::count(h->conv_batch.begin(), h->conv_batch.end(), b); };
       int b0 = 0;
       while (b0 < B) {
-        auto has = [&](int b) { return std::find(h->conv_batch.begin(), h->conv_batch.end(), b) != h->conv_batch.end(); };
-        const bool subj = has(b0);
+        const int ng = groups(b0);
         int b1 = b0 + 1;
-        while (b1 < B && has(b1) == subj) ++b1;
+        while (b1 < B && groups(b1) == ng) ++b1;
         const int nb = b1 - b0;
         AF_TRY(R.attention(q.p, C, (long)N * C, kv.kv, 2 * C, (long)S * 2 * C, vptr, 2 * C, (long)S * 2 * C, a, N,
-                           subj ? S - 9 : S, w.heads, w.dh, b0, nb, subj ? lse : nullptr));
-        if (subj && !R.dry) {
+                           S - ng * nt, w.heads, w.dh, b0, nb, ng ? lse : nullptr));
+        for (int gi = 0; gi < ng && !R.dry; ++gi) {
           const float scale = 1.0f / sqrtf((float)w.dh);
+          const int tok0 = S - (ng - gi) * nt;
           AF_TRY(DISPATCH(R.dt,
                           af_launch_conv_attn<bf16>(R.elem_ptr(q.p, (long)b0 * N * C), C, (long)N * C,
-                                                    R.elem_ptr(kv.kv, (long)b0 * S * 2 * C), 2 * C, (long)S * 2 * C, S, s9, lse,
+                                                    R.elem_ptr(kv.kv, (long)b0 * S * 2 * C), 2 * C, (long)S * 2 * C, tok0, s9, lse,
                                                     R.elem_ptr(a.p, (long)b0 * N * a.ld), a.ld, (long)N * a.ld, nb, N, w.heads,
-                                                    w.dh, H, W, scale, R.s),
+                                                    w.dh, H, W, scale, h->conv_ks, R.s),
                           af_launch_conv_attn<float>(R.elem_ptr(q.p, (long)b0 * N * C), C, (long)N * C,
-                                                     R.elem_ptr(kv.kv, (long)b0 * S * 2 * C), 2 * C, (long)S * 2 * C, S, s9, lse,
+                                                     R.elem_ptr(kv.kv, (long)b0 * S * 2 * C), 2 * C, (long)S * 2 * C, tok0, s9, lse,
                                                      R.elem_ptr(a.p, (long)b0 * N * a.ld), a.ld, (long)N * a.ld, nb, N, w.heads,
-                                                     w.dh, H, W, scale, R.s)));
+                                                     w.dh, H, W, scale, h->conv_ks, R.s)));
         }
         b0 = b1;
       }
@@ -1728,13 +1732,14 @@ int af_create(int device_id, const af_config* cfg, af_handle** out) {
   if (cfg->build_unet) {
     if (cfg->n_channel_mult <= 0 || cfg->n_channel_mult > 8 || cfg->n_attention_resolutions > 8) {
       af_set_error_msg("af_create: bad channel_mult / attention_resolutions");
+      af_destroy(h.release());
       return AF_ERR_INVALID;
     }
     int rc = build_unet(b);
     if (rc) { af_destroy(h.release()); return rc; }
   }
   if (cfg->build_vae) {
-    if (cfg->n_vae_ch_mult <= 0 || cfg->n_vae_ch_mult > 8) { af_set_error_msg("af_create: bad vae_ch_mult"); return AF_ERR_INVALID; }
+    if (cfg->n_vae_ch_mult <= 0 || cfg->n_vae_ch_mult > 8) { af_set_error_msg("af_create: bad vae_ch_mult"); af_destroy(h.release()); return AF_ERR_INVALID; }
     int rc = build_vae(b);
     if (rc) { af_destroy(h.release()); return rc; }
     if (cfg->build_vae_encoder) {
@@ -1744,12 +1749,16 @@ int af_create(int device_id, const af_config* cfg, af_handle** out) {
     }
   }
   if (cfg->build_clip) {
-    if (cfg->clip_vocab <= 0 || cfg->clip_layers <= 0 || cfg->clip_max_pos <= 0) { af_set_error_msg("af_create: bad CLIP config"); return AF_ERR_INVALID; }
+    if (cfg->clip_vocab <= 0 || cfg->clip_layers <= 0 || cfg->clip_max_pos <= 0) { af_set_error_msg("af_create: bad CLIP config"); af_destroy(h.release()); return AF_ERR_INVALID; }
     int rc = build_clip(b);
     if (rc) { af_destroy(h.release()); return rc; }
   }
   if (b.rc) { af_destroy(h.release()); return b.rc; }
-  HIP_CHECK_RET(hipDeviceSynchronize());
+  if (hipError_t e = hipDeviceSynchronize(); e != hipSuccess) {
+    af_set_error_msg("af_create: %s", hipGetErrorString(e));
+    af_destroy(h.release());
+    return AF_ERR_HIP;
+  }
   *out = h.release();
   return 0;
 }
@@ -1859,11 +1868,11 @@ int af_set_conv_attn(af_handle* h, int ks, int n_subj, const int* batch_idx, con
     h->ctx_set = false;
     return AF_OK;
   }
-  if (ks != 3) { af_set_error_msg("af_set_conv_attn: kernel size %d (only 3x3 is built)", ks); return AF_ERR_INVALID; }
+  if (ks > 4) { af_set_error_msg("af_set_conv_attn: kernel size %d (the reference has 2, 3 and 4: ldm/util.py:747-760)", ks); return AF_ERR_INVALID; }
   if (!batch_idx || !token_idx) { af_set_error_msg("af_set_conv_attn: null index arrays"); return AF_ERR_INVALID; }
   h->conv_ks = ks;
   h->conv_batch.assign(batch_idx, batch_idx + n_subj);
-  h->conv_tokens.assign(token_idx, token_idx + (size_t)n_subj * 9);
+  h->conv_tokens.assign(token_idx, token_idx + (size_t)n_subj * ks * ks);
   h->ctx_set = false;   // the cached K/V depend on the token order: af_set_context must follow
   return AF_OK;
 }
@@ -1896,27 +1905,35 @@ int af_set_context(af_handle* h, const float* ctx_dev, int Bf, int n_tokens, int
       HIP_CHECK_RET(hipMalloc(&h->ctx_kv[i].kv, (size_t)Bf * n_tokens * 2 * C * esize(dt)));
     }
   }
-  if (h->conv_ks == 3 && !h->conv_batch.empty()) {
-    // conv attention: in the samples that carry the subject, move its nine tokens (tap order) to the END of the token
+  if (h->conv_ks >= 2 && !h->conv_batch.empty()) {
+    const int nt = h->conv_ks * h->conv_ks;
+    // conv attention: in the samples that carry the subject, move its ks^2 tokens (tap order) to the END of the token
     // list of every context layer -- softmax is invariant to the key order, and the flash kernel can then leave them
     // out by key count.  Row r of the cast context = (sample b, layer l, token i).
-    if (n_tokens <= 9) { af_set_error_msg("af_set_context: conv attention needs more than 9 tokens"); return AF_ERR_INVALID; }
+    if (n_tokens <= nt) { af_set_error_msg("af_set_context: conv attention needs more than %d tokens", nt); return AF_ERR_INVALID; }
     const size_t rows = (size_t)Bf * L * n_tokens;
     std::vector<int> map(rows);
     for (int b = 0; b < Bf; ++b) {
       std::vector<int> order(n_tokens);
       for (int i = 0; i < n_tokens; ++i) order[i] = i;
-      auto it = std::find(h->conv_batch.begin(), h->conv_batch.end(), b);
-      if (it != h->conv_batch.end()) {
-        const int* tk = &h->conv_tokens[(size_t)(it - h->conv_batch.begin()) * 9];
-        std::vector<char> is_subj(n_tokens, 0);
-        for (int j = 0; j < 9; ++j) {
+      // every (sample, subject string) entry of af_set_conv_attn for this sample, in the order given: their tokens go to
+      // the end of the list group by group
+      std::vector<int> tail;
+      std::vector<char> is_subj(n_tokens, 0);
+      for (size_t e = 0; e < h->conv_batch.size(); ++e) {
+        if (h->conv_batch[e] != b) continue;
+        const int* tk = &h->conv_tokens[e * nt];
+        for (int j = 0; j < nt; ++j) {
           if (tk[j] < 0 || tk[j] >= n_tokens || is_subj[tk[j]]) { af_set_error_msg("af_set_context: bad subject token index %d", tk[j]); return AF_ERR_INVALID; }
           is_subj[tk[j]] = 1;
+          tail.push_back(tk[j]);
         }
+      }
+      if (!tail.empty()) {
+        if ((int)tail.size() >= n_tokens) { af_set_error_msg("af_set_context: conv attention leaves no ordinary token in sample %d", b); return AF_ERR_INVALID; }
         int o = 0;
         for (int i = 0; i < n_tokens; ++i) if (!is_subj[i]) order[o++] = i;
-        for (int j = 0; j < 9; ++j) order[o++] = tk[j];
+        for (int v : tail) order[o++] = v;
       }
       for (int l = 0; l < L; ++l)
         for (int i = 0; i < n_tokens; ++i)
@@ -2165,6 +2182,11 @@ int af_prof_reset(void) {
   g_prof_pool_used = 0;
   for (int c = 0; c < AF_K_COUNT; ++c) g_af_prof_seen[c] = 0;
   return 0;
+}
+double af_flops_issued(int reset) {
+  const double v = g_af_flops_issued;
+  if (reset) g_af_flops_issued = 0.0;
+  return v;
 }
 int af_prof_set_stride(int every) {
   if (every < 1) { af_set_error_msg("af_prof_set_stride: stride must be >= 1"); return AF_ERR_INVALID; }

@@ -6,6 +6,7 @@
 #include "../../include/adaface_hip.h"
 #include "af_kernels.h"
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -39,7 +40,82 @@ inline int rup(int a, int b) { return (a + b - 1) / b * b; }
   void* var = tmp.get((bytes), (zero));                          \
   if (!var) { af_set_error_msg("hipMalloc failed in op"); return AF_ERR_HIP; }
 
+// ---- device clock probe (bench.py stamps every line with it: devices of one pool hold different clocks under MFMA load, so
+// whole-path numbers from different boxes are only comparable through a number like this) ----
+// Every wave runs `iters` rounds of four independent v_mfma_f32_32x32x16_bf16 on pseudo-random register operands (no memory
+// traffic, no LDS) between two (s_memtime, s_memrealtime) stamp pairs: shader cycles / 100 MHz reference ticks = the clock
+// the chip holds under a dense MFMA stream.  The stamps go to a buffer nothing else reads; the accumulators to a sink.
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* __restrict__ stamps, float* __restrict__ sink,
+                                                          int iters) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned hsh = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+  bf16x8 a, b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    hsh = hsh * 1664525u + 1013904223u;
+    a[e] = (bf16)(((int)(hsh >> 16) & 0xFF) * (1.0f / 128.0f) - 1.0f);
+    hsh = hsh * 1664525u + 1013904223u;
+    b[e] = (bf16)(((int)(hsh >> 16) & 0xFF) * (1.0f / 128.0f) - 1.0f);
+  }
+  f32x16 c0, c1, c2, c3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; c2[r] = 0.f; c3[r] = 0.f; }
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, c3, 0, 0, 0);
+  }
+  asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0) {
+    stamps[((size_t)blockIdx.x * 4 + wave) * 2 + 0] = t1 - t0;
+    stamps[((size_t)blockIdx.x * 4 + wave) * 2 + 1] = r1 - r0;
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc += c0[r] + c1[r] + c2[r] + c3[r];
+  sink[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 extern "C" {
+
+int af_clock_probe(void* stream, int iters, double* mfma_mhz, double* mfma_tflops) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (iters <= 0) iters = 40000;
+  hipDeviceProp_t prop;
+  int dev = 0;
+  HIP_CHECK_RET(hipGetDevice(&dev));
+  HIP_CHECK_RET(hipGetDeviceProperties(&prop, dev));
+  const int blocks = 2 * prop.multiProcessorCount;    // two waves per SIMD: every matrix pipe is kept busy
+  Tmp tmp;
+  OP_ALLOC(stamps, (size_t)blocks * 4 * 2 * sizeof(unsigned long long), true);
+  OP_ALLOC(sink, (size_t)blocks * 256 * sizeof(float), false);
+  hipEvent_t e0, e1;
+  HIP_CHECK_RET(hipEventCreate(&e0));
+  HIP_CHECK_RET(hipEventCreate(&e1));
+  // one short launch to wake the device, then the timed one
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, s, (unsigned long long*)stamps, (float*)sink, 2000);
+  HIP_CHECK_RET(hipEventRecord(e0, s));
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, s, (unsigned long long*)stamps, (float*)sink, iters);
+  HIP_CHECK_RET(hipEventRecord(e1, s));
+  HIP_CHECK_RET(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_CHECK_RET(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  std::vector<unsigned long long> h((size_t)blocks * 8);
+  HIP_CHECK_RET(hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  std::vector<double> mhz;
+  for (size_t i = 0; i < h.size(); i += 2)
+    if (h[i + 1] > 0) mhz.push_back((double)h[i] / (double)h[i + 1] * 100.0);
+  if (mhz.empty()) { af_set_error_msg("af_clock_probe: no stamps"); return AF_ERR_STATE; }
+  std::sort(mhz.begin(), mhz.end());
+  if (mfma_mhz) *mfma_mhz = mhz[mhz.size() / 2];
+  if (mfma_tflops) *mfma_tflops = (double)blocks * 4 * (double)iters * 4 * (2.0 * 32 * 32 * 16) / (ms * 1e-3) / 1e12;
+  return AF_OK;
+}
 
 int af_op_conv2d(int dtype, const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev,
                  float* y_dev, int B, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int upsample,
@@ -310,14 +386,23 @@ int af_op_layernorm(int dtype, const float* x_dev, const float* gamma_dev, const
 }
 
 int af_op_attention(int dtype, const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int B, int Nq,
-                    int Nk, int heads, int dh, float scale, int causal, void* stream) {
+                    int Nk, int heads, int dh, float scale, int causal, void* stream) {   // causal = flags: bit 0 causal, bit 1 NaN guard rows
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Tmp tmp;
   const int C = heads * dh;
   const long nq = (long)B * Nq * C, nk = (long)B * Nk * C;
   OP_ALLOC(qn, (size_t)nq * esz(dtype), false);
-  OP_ALLOC(kn, (size_t)nk * esz(dtype), false);
-  OP_ALLOC(vn, (size_t)nk * esz(dtype), false);
+  // flags bit 1 (test hook): K and V are the heads of larger allocations whose 128 tail rows hold NaNs, so a kernel that
+  // reads rows >= Nk of the last sample's last key tile (instead of having them zero-filled) shows up as NaN in O
+  const bool guard = (causal & 2) != 0;
+  causal &= 1;
+  const size_t tail = guard ? (size_t)128 * C * esz(dtype) : 0;
+  OP_ALLOC(kn, (size_t)nk * esz(dtype) + tail, false);
+  OP_ALLOC(vn, (size_t)nk * esz(dtype) + tail, false);
+  if (guard) {
+    if (hipMemsetAsync((char*)kn + (size_t)nk * esz(dtype), 0xFF, tail, s) != hipSuccess ||   // 0xFFFF / 0xFFFFFFFF: NaN
+        hipMemsetAsync((char*)vn + (size_t)nk * esz(dtype), 0xFF, tail, s) != hipSuccess) return AF_ERR_HIP;
+  }
   OP_ALLOC(on, (size_t)nq * esz(dtype), true);
   OP_TRY(DISP(dtype, af_launch_cast_f32<bf16>(q_dev, qn, nq, s), af_launch_cast_f32<float>(q_dev, qn, nq, s)));
   OP_TRY(DISP(dtype, af_launch_cast_f32<bf16>(k_dev, kn, nk, s), af_launch_cast_f32<float>(k_dev, kn, nk, s)));

@@ -138,14 +138,15 @@ class Engine:
               "af_set_context")
 
     def set_conv_attn(self, ks: int, batch_idx=(), token_idx=()):
-        """Subject-token conv attention (attention.py:208-216): `batch_idx` samples carry the subject whose first nine
-        token positions are `token_idx[i]`.  ks <= 1 or no samples switches it off.  Invalidates the cached context."""
+        """Subject-token conv attention (attention.py:208-216), kernel size ks = 2, 3 or 4: sample `batch_idx[i]` carries a
+        subject string whose first ks*ks token positions are `token_idx[i]` (a sample with several subject strings appears
+        once per string).  ks <= 1 or no samples switches it off.  Invalidates the cached context."""
         n = len(batch_idx)
         bi = (C.c_int * max(n, 1))(*[int(b) for b in batch_idx])
         flat = [int(t) for row in token_idx for t in row]
         ti = (C.c_int * max(len(flat), 1))(*flat)
-        if n and len(flat) != 9 * n:
-            raise ValueError("set_conv_attn: nine token positions per subject sample")
+        if n and len(flat) != ks * ks * n:
+            raise ValueError(f"set_conv_attn: {ks * ks} token positions per subject sample for a {ks}x{ks} kernel")
         check(self._lib.af_set_conv_attn(self._h, int(ks), n, bi, ti), "af_set_conv_attn")
         self._ctx_key = None
 

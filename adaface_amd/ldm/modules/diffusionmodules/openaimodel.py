@@ -114,21 +114,29 @@ class UNetModel(HipModule):
     def _conv_attn_spec(ks, placeholder2indices):
         """(ks, batch indices, token positions) for Engine.set_conv_attn from the reference's
         extra_info['placeholder2indices'] = {subject string: (indices_B, indices_N)} (util.py:711-727): the M >= ks*ks
-        positions of each subject sample are consecutive in indices_N; the first ks*ks are used."""
+        positions of each subject sample are consecutive in indices_N; the first ks*ks are used.  Every subject string of
+        the dict contributes its own rows (attention.py:208-216 loops over them); a sample that carries several strings
+        appears once per string, in the dict's order.  Kernel sizes 2, 3, 4 as the reference (util.py:747-760)."""
         if ks is None or ks <= 1 or not placeholder2indices:
             return (0, (), ())
-        if ks != 3:
-            raise NotImplementedError(f"conv attention kernel size {ks}: only 3x3 (the inference setting) is built")
-        if len(placeholder2indices) != 1:
-            raise NotImplementedError("conv attention with several subject strings in one batch")
-        idx_b, idx_n = next(iter(placeholder2indices.values()))
-        idx_b = [int(v) for v in torch.as_tensor(idx_b).tolist()]
-        idx_n = [int(v) for v in torch.as_tensor(idx_n).tolist()]
-        uniq = sorted(set(idx_b))
-        M = len(idx_n) // len(uniq)
-        if M < ks * ks:
-            raise ValueError(f"{M} embeddings are not enough to cover a {ks}x{ks} kernel")
-        return (ks, tuple(uniq), tuple(tuple(idx_n[i * M: i * M + ks * ks]) for i in range(len(uniq))))
+        if ks not in (2, 3, 4):
+            raise NotImplementedError(f"conv attention kernel size {ks}: the reference pads for 2, 3 and 4 only (util.py:747-760)")
+        batch, tokens = [], []
+        for indices in placeholder2indices.values():
+            if indices is None:
+                continue
+            idx_b = [int(v) for v in torch.as_tensor(indices[0]).tolist()]
+            idx_n = [int(v) for v in torch.as_tensor(indices[1]).tolist()]
+            if not idx_b:
+                continue
+            uniq = sorted(set(idx_b))
+            M = len(idx_n) // len(uniq)
+            if M < ks * ks:
+                raise ValueError(f"{M} embeddings are not enough to cover a {ks}x{ks} kernel")
+            for i, bi in enumerate(uniq):
+                batch.append(bi)
+                tokens.append(tuple(idx_n[i * M: i * M + ks * ks]))
+        return (ks, tuple(batch), tuple(tokens))
 
     @torch.no_grad()
     def forward(self, x, timesteps=None, context=None, y=None, context_in=None, extra_info=None, cfg_twin=False, **kwargs):

@@ -140,9 +140,9 @@ def layer_norm(x, weight, bias, eps=1e-5, dtype="bf16"):
     return y
 
 
-def attention(q, k, v, heads, scale=None, dtype="bf16", causal=False):
+def attention(q, k, v, heads, scale=None, dtype="bf16", causal=False, nan_guard=False):
     """softmax(q k^T * scale) v per head; q [B,N,heads*dh], k/v [B,S,heads*dh] (attention.py:197-243).  causal: query i
-    attends to keys <= i (the CLIP text tower's mask)."""
+    attends to keys <= i (the CLIP text tower's mask).  nan_guard (tests): K / V sit in front of 128 rows of NaNs."""
     lib = _lib.load()
     q, k, v = _dev_f32(q), _dev_f32(k), _dev_f32(v)
     B, Nq, Cn = q.shape
@@ -151,7 +151,7 @@ def attention(q, k, v, heads, scale=None, dtype="bf16", causal=False):
     scale = dh ** -0.5 if scale is None else scale
     o = torch.empty_like(q)
     check(lib.af_op_attention(DTYPES[dtype], ptr(q), ptr(k), ptr(v), ptr(o), B, Nq, Nk, heads, dh, scale,
-                              1 if causal else 0, stream_ptr()),
+                              (1 if causal else 0) | (2 if nan_guard else 0), stream_ptr()),
           "af_op_attention")
     return o
 

@@ -19,6 +19,10 @@ import torch
 import torch.distributed as dist
 
 
+# what the process group did in this process (bench.py reports it: "did RCCL see N ranks" must be checkable from the line)
+STATS = {"backend": None, "world_size": 1, "probe_allreduce": None, "all_gather_calls": 0}
+
+
 def free_port() -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
@@ -40,7 +44,11 @@ def launch_ranks(n_ranks: int, script: str, argv: Sequence[str], env: Optional[d
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, *argv]
     e = dict(os.environ if env is None else env)
-    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL cannot exchange buffer handles without it here
+    # The build / GPU images export HSA_ENABLE_IPC_MODE_LEGACY=0 and document why: the host driver of this pool only supports
+    # dmabuf IPC, and without it buffer-handle exchange between processes (RCCL's intra-node transport, CUDA-tensor sharing)
+    # fails with `hipIpcGetMemHandle: invalid argument`.  Inherited when set; defaulted for a caller that scrubbed its env.
+    # (A world-1 run -- all this build can execute, tests/test_chained_gpu.py -- exchanges no handles and cannot show it.)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=e).returncode
 
 
@@ -64,6 +72,7 @@ def init_distributed(expected_world: int, backend: str = "nccl", device: Optiona
     probe[rank] = 1 + (device.index if (backend == "nccl" and device is not None and device.index is not None) else rank)
     dist.all_reduce(probe)
     seen = probe.cpu().tolist()
+    STATS.update(backend=backend, world_size=world, probe_allreduce=seen)
     if world != expected_world or any(v == 0 for v in seen):
         raise SystemExit(f"process group has {world} ranks ({seen}), --gpus asked for {expected_world}")
     if backend == "nccl" and len(set(seen)) != world:
@@ -105,8 +114,9 @@ def gather_frames(frames: torch.Tensor, global_batch: Optional[int] = None) -> t
     """All-gather decoded frames [b_local, H, W, 3] (uint8) -> [global_batch, H, W, 3] on every rank, in global
     sample order.  Equal shards use one all_gather_into_tensor; ragged shards pad to the largest shard."""
     rank, w = world()
-    if w == 1:
-        return frames
+    if w == 1 and not (dist.is_available() and dist.is_initialized()):
+        return frames                      # no process group: plain single-process run
+    # (a world-1 group still runs the collective: the one-rank launch exercises the same RCCL call as N ranks)
     b_local = frames.shape[0]
     if global_batch is None:
         n = torch.tensor([b_local], device=frames.device, dtype=torch.int64)
@@ -117,10 +127,12 @@ def gather_frames(frames: torch.Tensor, global_batch: Optional[int] = None) -> t
     if len(set(counts)) == 1:
         out = torch.empty((global_batch,) + tuple(frames.shape[1:]), dtype=frames.dtype, device=frames.device)
         dist.all_gather_into_tensor(out, frames.contiguous())
+        STATS["all_gather_calls"] += 1
         return out
     bmax = max(counts)
     padded = torch.zeros((bmax,) + tuple(frames.shape[1:]), dtype=frames.dtype, device=frames.device)
     padded[:b_local] = frames
     bufs = [torch.empty_like(padded) for _ in range(w)]
     dist.all_gather(bufs, padded)
+    STATS["all_gather_calls"] += 1
     return torch.cat([bufs[r][:counts[r]] for r in range(w)], dim=0)

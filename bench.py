@@ -167,7 +167,7 @@ def main():
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
         rank, world = init_distributed(args.gpus, backend="nccl", device=device)
-    from adaface_amd.parallel import gather_frames, shard_batch
+    from adaface_amd.parallel import STATS, gather_frames, shard_batch
     from adaface_amd.synth import synth_context, synth_context_adaprompt, synth_context_identity
 
     B, S = args.batch, args.ddim_steps
@@ -220,9 +220,20 @@ def main():
         if not stub:
             torch.cuda.synchronize()
 
+    # held-clock proxy of THIS device, taken before the warm-up: devices of one pool differ by +-5 % on MFMA-dense kernels
+    clock = None
+    if lib is not None:
+        mhz, tfl = C.c_double(0.0), C.c_double(0.0)
+        _lib.check(lib.af_clock_probe(C.c_void_p(torch.cuda.current_stream().cuda_stream), 0, C.byref(mhz), C.byref(tfl)),
+                   "af_clock_probe")
+        clock = {"mfma_loop_mhz": mhz.value, "mfma_loop_tflops": tfl.value,
+                 "what": "register-only v_mfma_f32_32x32x16_bf16 loop, two waves per SIMD on every CU, ~5 ms, before the warm-up: "
+                         "median in-kernel clock (s_memtime / s_memrealtime) and its rate"}
     for _ in range(args.warmup):
         step()
     fence()
+    if lib is not None:
+        lib.af_flops_issued(1)
     timing = not args.no_kernel_timing and not stub
     if timing:
         lib.af_prof_reset()
@@ -233,8 +244,10 @@ def main():
         out = step()
     fence()
     dt = time.perf_counter() - t0
+    flops_executed = None
     if lib is not None:
         lib.af_prof_enable(0)
+        flops_executed = float(lib.af_flops_issued(1))   # this rank's GEMM / conv / attention FLOPs inside the timed region
     assert out.shape[0] == G and out.shape[-1] == 3 and out.dtype == torch.uint8
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -326,6 +339,14 @@ def main():
                        "global_batch": G, "latent": [4, 64, 64], "guidance_scale": [10.0, 4.0], "parallelism": f"dp{world}"},
             "whole_path_algorithmic_tflops": value * flop_img / 1e12 / world,
             "whole_path_frac_of_mfma_peak": value * flop_img / world / (PEAK_F32 if args.dtype == "f32" else PEAK_BF16),
+            # the same with the FLOPs the kernels were actually handed (rank 0's launches in the timed region): the four-phase
+            # upsamplers run 4/9 of the reference's MACs and the CFG twin forward shares the context-independent prefix, so
+            # this is the number to read as MFMA utilisation; the line above is the metric SURVEY.md 8(d) defines
+            "whole_path_executed_flops_frac": (flops_executed / dt / (PEAK_F32 if args.dtype == "f32" else PEAK_BF16)
+                                               if flops_executed else None),
+            "executed_over_reference_flops": (flops_executed / (images / world * flop_img) if flops_executed else None),
+            "device_clock_probe": clock,
+            "distributed": dict(STATS),
             "roofline": roof, "kernels": kernels, "parity": parity,
         }
         if stub:

@@ -79,8 +79,9 @@ int af_tensor_shape(af_handle* h, int i, int64_t* shape4 /* up to 4 dims, 0-term
 /* Subject-token convolutional attention inside the UNet's cross-attention layers
  * (extra_info['use_conv_attn_kernel_size'] / ['placeholder2indices'], openaimodel.py:852-853,922-945;
  * CrossAttention.forward attention.py:208-216; replace_rows_by_conv_attn ldm/util.py:701-879).
- * ks = 3 (<= 1 or n_subj = 0 switches it off); batch_idx[n_subj] = samples of the CFG batch that carry the subject,
- * token_idx[n_subj][9] = text positions of its first nine embeddings in tap order (host arrays).  Applies to every
+ * ks = 2, 3 or 4 (ldm/util.py:747-760; <= 1 or n_subj = 0 switches it off); batch_idx[n_subj] = samples of the CFG batch
+ * that carry the subject, token_idx[n_subj][ks*ks] = text positions of its first ks*ks embeddings in tap order (host
+ * arrays).  Applies to every
  * conditioned layer except CA layers 6-10, as the reference.  Must be followed by af_set_context. */
 int af_set_conv_attn(af_handle* h, int ks, int n_subj, const int* batch_idx, const int* token_idx);
 /* get_layer_context + to_k/to_v of all cross-attention layers, hoisted out of the
@@ -175,6 +176,15 @@ int af_prof_reset(void);
 /* time only every `every`-th launch of a class (default 1 = all).  An event pair costs ~9 us of stream time, so
  * bench.py samples (every = 7) inside its timed region; sums and launch counts then cover the sampled launches. */
 int af_prof_set_stride(int every);
+/* FLOPs (2 x MAC) handed to the GEMM / convolution / attention kernels since the last reset: what the path EXECUTES
+ * (bench.py: whole_path_executed_flops_frac; the phase-decomposed upsamplers and the shared CFG prefix execute fewer than
+ * the reference's algorithm counts).  reset != 0 zeroes the counter after reading. */
+double af_flops_issued(int reset);
+/* Device clock probe: a register-only bf16 MFMA loop (`iters` rounds of four v_mfma_f32_32x32x16_bf16 per wave, two waves
+ * per SIMD on every CU; <= 0: 40000 rounds, about 5 ms) stamped with s_memtime / s_memrealtime.  mfma_mhz = median in-kernel
+ * clock the chip held under it, mfma_tflops = its rate.  bench.py stamps each line with both so that lines measured on
+ * different devices of a pool can be compared. */
+int af_clock_probe(void* stream, int iters, double* mfma_mhz, double* mfma_tflops);
 int af_prof_collect(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes);
 /* microseconds an EMPTY event pair measures on `stream` (mean of n): the bracket's own cost inside every timed launch */
 double af_prof_event_overhead_us(void* stream, int n);
@@ -241,8 +251,9 @@ int af_op_layernorm_fp8(const float* x_dev, const float* gamma_dev, const float*
 /* F.layer_norm over the last dim of [rows, C]. */
 int af_op_layernorm(int dtype, const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps,
                     float* y_dev, int64_t rows, int C, void* stream);
-/* multi-head attention on [B,N,heads*dh] / [B,S,heads*dh] tensors (attention.py:197-243); causal != 0: query i sees
- * keys <= i (CLIP text tower). */
+/* multi-head attention on [B,N,heads*dh] / [B,S,heads*dh] tensors (attention.py:197-243); `causal` is a flag word:
+ * bit 0: query i sees keys <= i (CLIP text tower); bit 1 (test hook): K and V are placed at the head of allocations
+ * whose 128 tail rows hold NaNs, so reads past row S of the last sample become visible in the output. */
 int af_op_attention(int dtype, const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int B, int Nq,
                     int Nk, int heads, int dh, float scale, int causal, void* stream);
 /* timestep_embedding (util.py:154-174): t [B] int64 -> y [B,dim] fp32. */

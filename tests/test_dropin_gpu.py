@@ -69,6 +69,33 @@ def test_apply_model_conv_attention_matches_reference(gpu, report, tiny_model, m
         assert np.abs(eps.cpu().numpy()[0] - g["tiny_eps"][0]).max() > 1e-4    # the replacement does something
 
 
+@pytest.mark.parametrize("case", ["k2", "k4", "multi"])
+def test_apply_model_conv_attention_kernel_sizes_and_several_strings(gpu, report, tiny_model, case):
+    """Conv attention with kernel sizes 2 and 4 (util.py:747-760) and with two subject strings in one batch, one sample
+    carrying both (attention.py:208-216), through the drop-in UNet vs the reference UNet's output."""
+    g = dict(np.load(GOLD / "golden_tiny.npz"))
+    x = torch.tensor(g["tiny_x"], device=gpu)
+    t = torch.tensor(g["tiny_t"], device=gpu)
+    emb, prompts, info = tiny_model.get_learned_conditioning(torch.tensor(g["tiny_ctx"], device=gpu))
+    z = (torch.tensor(g["tiny_convattn_idx_b"]), torch.tensor(g["tiny_convattn_idx_n"]))
+    if case == "k2":
+        ph, ks, ref = {"z": z}, 2, g["tiny_convattn_k2_eps"]
+    elif case == "k4":
+        ph, ks, ref = {"z": (torch.tensor(g["tiny_convattn_k4_idx_b"]), torch.tensor(g["tiny_convattn_k4_idx_n"]))}, 4, g["tiny_convattn_k4_eps"]
+    else:
+        ph = {"z": z, "y": (torch.tensor(g["tiny_convattn_multi_y_idx_b"]), torch.tensor(g["tiny_convattn_multi_y_idx_n"]))}
+        ks, ref = 3, g["tiny_convattn_multi_eps"]
+    for mode, tol in (("f32", 2e-4), ("bf16", 3e-2)):
+        tiny_model.set_compute_dtype(mode)
+        try:
+            eps = tiny_model.apply_model(x, t, (emb, prompts, dict(info, use_conv_attn_kernel_size=ks, placeholder2indices=ph)))
+        finally:
+            tiny_model.set_compute_dtype("f32")
+        err = np.abs(eps.cpu().numpy() - ref).max() / np.abs(ref).max()
+        report(f"dropin apply_model + conv attention {case} vs reference golden [{mode}]", err, float(np.abs(ref).max()), tol)
+        assert err < tol, (case, mode, err)
+
+
 def test_apply_model_compel_cfg_matches_reference(gpu, report, tiny_model):
     """Inference-time compel cfg (stable_txt2img.py:680-682 -> openaimodel.py:898-916): context of the cond half
     re-weighted against the empty prompt's, every layer (prob 1, level 2)."""
@@ -123,6 +150,35 @@ def test_ddim_sampler_matches_reference_sampler(gpu, report, tiny_model):
     err = np.abs(s6.cpu().numpy() - ref).max() / np.abs(ref).max()
     report("dropin DDIMSampler S=6 (7 steps) vs reference sampler [f32]", err, float(np.abs(ref).max()), 1e-3)
     assert err < 1e-3
+
+
+def test_ddim_sampler_inpainting_matches_reference_sampler(gpu, report, tiny_model):
+    """The inpainting branch of ddim_sampling (ddim.py:190-195: img = q_sample(x0, ts) * mask + (1 - mask) * img in front of
+    every step) through the drop-in sampler and LatentDiffusion.q_sample, against the REFERENCE sampler's latent.  q_sample
+    draws fresh noise at every step (ddpm.py:421); the golden records the five draws and the test replays them."""
+    from ldm.models.diffusion.ddim import DDIMSampler
+    g = dict(np.load(GOLD / "golden_tiny.npz"))
+    c = tiny_model.get_learned_conditioning(torch.tensor(g["ddim_c"], device=gpu))
+    uc = tiny_model.get_learned_conditioning(torch.tensor(g["ddim_uc"], device=gpu))
+    noises = [torch.tensor(n, device=gpu) for n in g["inpaint_q_noise"]]
+    orig = tiny_model.q_sample
+    calls = []
+
+    def q_sample(x_start, t, noise=None):
+        calls.append(int(t[0].item()))
+        return orig(x_start, t, noise=noises[len(calls) - 1])
+    object.__setattr__(tiny_model, "q_sample", q_sample)
+    try:
+        samples, _ = DDIMSampler(tiny_model).sample(
+            S=5, conditioning=c, batch_size=1, shape=[4, 16, 16], verbose=False, guidance_scale=[8.0, 3.0],
+            unconditional_conditioning=uc, eta=0.0, x_T=torch.tensor(g["ddim_xT"], device=gpu),
+            mask=torch.tensor(g["inpaint_mask"], device=gpu), x0=torch.tensor(g["inpaint_x0"], device=gpu))
+    finally:
+        object.__delattr__(tiny_model, "q_sample")
+    ref = g["inpaint_S5_samples"]
+    err = np.abs(samples.cpu().numpy() - ref).max() / np.abs(ref).max()
+    report("dropin DDIMSampler inpainting (mask, x0, q_sample) S=5 vs reference sampler [f32]", err, float(np.abs(ref).max()), 1e-3)
+    assert calls == [801, 601, 401, 201, 1] and err < 1e-3, (calls, err)
 
 
 def test_img2img_encode_decode_matches_reference_sampler(gpu, report, tiny_model):

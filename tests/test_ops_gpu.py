@@ -503,10 +503,31 @@ def test_attention_spiky_bf16_dh40(gpu, report, knobs, ring, spike):
     if spike <= 8:
         _cmp(report, f"attention spiky dh40 ring{ring} spike{spike:g}", got, ref, "bf16")
     else:
-        # scores of +-100 and more between unrelated queries and the spiked keys: the bf16 rounding of the pre-scaled Q
-        # (2^-9 relative) moves such scores by tenths of a unit, so rows with two large competing scores are only
-        # compared loosely; the rows under test are the spiked ones below
-        _cmp(report, f"attention spiky dh40 ring{ring} spike{spike:g}", got, ref, "bf16", tol_scale=4.0)
+        # The kernels round the pre-scaled Q (q * scale * log2 e) to bf16: component d of a query moves by <= 2^-9 relative, so
+        # the score against key j moves by <= delta_ij = 2^-9 * scale * log2(e) * sum_d |q_id| |k_jd| units of the log2
+        # domain -- tenths of a unit against the spiked keys (|k| = 24 |q|), whatever the score itself is.  To first order
+        # that moves row i of the output by <= E_i = ln 2 * sum_j p_ij delta_ij max_d |v_jd - o_id|.  The bar is PER ROW:
+        # the normal bf16 bar plus that row's own bound (no global loosening); the emulation of exactly this rounding on
+        # the CPU stays below 0.55 E_i on every row.
+        sl2 = dh ** -0.5 * math.log2(math.e)
+        qh = q.view(B, N, heads, dh).transpose(1, 2)
+        kh = k.view(B, N, heads, dh).transpose(1, 2)
+        vh = v.view(B, N, heads, dh).transpose(1, 2)
+        pr = torch.softmax(torch.einsum("bhid,bhjd->bhij", qh, kh) * dh ** -0.5, dim=-1)
+        oh = torch.einsum("bhij,bhjd->bhid", pr, vh)
+        delta = torch.einsum("bhid,bhjd->bhij", qh.abs(), kh.abs()) * sl2 * 2.0 ** -9
+        dv = (vh.unsqueeze(2) - oh.unsqueeze(3)).abs().amax(-1)
+        E = math.log(2.0) * (pr * delta * dv).sum(-1)                                      # [B, H, N]
+        scale = ref.abs().max().item()
+        err = (got.cpu() - ref).abs().view(B, N, heads, dh).amax(-1).transpose(1, 2)      # [B, H, N]
+        bar = TOL["bf16"] * scale + E
+        worst = (err / bar).max().item()
+        report(f"attention spiky dh40 ring{ring} spike{spike:g}: worst row error / (bf16 bar + the row's Q-rounding bound)[bf16]",
+               worst, 1.0, 1.0)
+        report(f"attention spiky dh40 ring{ring} spike{spike:g}: rows whose bound is below the bf16 bar[bf16]",
+               (err * (E < TOL["bf16"] * scale)).max().item(), scale, 2.0 * TOL["bf16"] * scale)
+        assert (E > TOL["bf16"] * scale).float().mean().item() < 0.25      # the loosened rows are a minority
+        assert worst <= 1.0, worst
     # the two spiked queries on their own: their output is essentially v[330] / v[470]
     assert (got[0, 17].cpu() - ref[0, 17]).abs().max() <= 1.5e-2 * ref.abs().max()
     assert (got[0, 300].cpu() - ref[0, 300]).abs().max() <= 1.5e-2 * ref.abs().max()
@@ -524,6 +545,24 @@ def test_attention_dh40_ring_shapes(gpu, report, B, Nq, Nk, heads):
     ref = _ref_attention(q, k, v, heads)
     got = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), heads, dtype="bf16")
     _cmp(report, f"attention ring N{Nq} S{Nk} h{heads} d40", got, ref, "bf16")
+
+
+@pytest.mark.parametrize("Nk", [77, 129])
+def test_attention_dh40_ring_nan_guard(gpu, report, Nk):
+    """the ring kernel zero-fills rows >= Nk of the last key tile through the buffer range check.  K and V are
+    placed in front of 128 rows of NaNs (af_op_attention flag bit 1): a kernel that really read those rows would turn
+    0 * NaN into NaN in O (finite garbage there is invisible: P is 0).  One run, finite and matching."""
+    from adaface_amd import ops
+    g = torch.Generator().manual_seed(1000 + Nk)
+    B, Nq, heads = 2, 512, 8
+    C = heads * 40
+    q = _q(torch.randn(B, Nq, C, generator=g), "bf16")
+    k = _q(torch.randn(B, Nk, C, generator=g), "bf16")
+    v = _q(torch.randn(B, Nk, C, generator=g), "bf16")
+    ref = _ref_attention(q, k, v, heads)
+    got = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), heads, dtype="bf16", nan_guard=True)
+    assert torch.isfinite(got).all(), "ring kernel read K/V rows past Nk"
+    _cmp(report, f"attention ring nan-guard S{Nk}", got, ref, "bf16")
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -162,6 +162,38 @@ def test_tiny_unet_conv_attention_matches_reference(tiny):
     assert np.array_equal(ref[1], tiny["tiny_eps"][1])           # ... and leaves the subject-free sample alone
 
 
+@pytest.mark.parametrize("case", ["k2", "k4", "multi"])
+def test_tiny_unet_conv_attention_kernel_sizes_and_several_strings(tiny, case):
+    """Kernel sizes 2 and 4 (asymmetric pads, util.py:747-760) and two subject strings in one batch (attention.py:208-216
+    loops over placeholder2indices) inside the reference UNet vs the oracle."""
+    cfg = O.TINY_UNET
+    sd = O.synth_state_dict(O.unet_param_shapes(cfg), seed=11)
+    z = (torch.tensor(tiny["tiny_convattn_idx_b"]), torch.tensor(tiny["tiny_convattn_idx_n"]))
+    if case == "k2":
+        ph, ks, ref = z, 2, tiny["tiny_convattn_k2_eps"]
+    elif case == "k4":
+        ph, ks, ref = (torch.tensor(tiny["tiny_convattn_k4_idx_b"]), torch.tensor(tiny["tiny_convattn_k4_idx_n"])), 4, tiny["tiny_convattn_k4_eps"]
+    else:
+        ph = {"z": z, "y": (torch.tensor(tiny["tiny_convattn_multi_y_idx_b"]), torch.tensor(tiny["tiny_convattn_multi_y_idx_n"]))}
+        ks, ref = 3, tiny["tiny_convattn_multi_eps"]
+    eps = O.unet_forward(sd, cfg, torch.tensor(tiny["tiny_x"]), torch.tensor(tiny["tiny_t"]), torch.tensor(tiny["tiny_ctx"]),
+                         placeholder_indices=ph, conv_attn_kernel_size=ks)
+    assert np.abs(eps.numpy() - ref).max() < 2e-5 * np.abs(ref).max()
+    assert np.abs(ref - tiny["tiny_convattn_eps"]).max() > 1e-4      # each case differs from the single-string 3x3 one
+
+
+def test_tiny_ddim_inpainting_matches_reference_sampler(tiny):
+    """The mask / x0 blend of ddim_sampling (ddim.py:190-195) with the recorded q_sample noise."""
+    cfg = O.TINY_UNET
+    sd = O.synth_state_dict(O.unet_param_shapes(cfg), seed=11)
+    apply = lambda x, t, c: O.unet_forward(sd, cfg, x, t, c)
+    out = O.ddim_sample(apply, O.register_schedule(), 5, torch.tensor(tiny["ddim_xT"]), torch.tensor(tiny["ddim_c"]),
+                        torch.tensor(tiny["ddim_uc"]), guidance_scale=(8.0, 3.0), mask=torch.tensor(tiny["inpaint_mask"]),
+                        x0=torch.tensor(tiny["inpaint_x0"]), q_noise=torch.tensor(tiny["inpaint_q_noise"]))
+    ref = tiny["inpaint_S5_samples"]
+    assert np.abs(out.numpy() - ref).max() < 1e-5 * np.abs(ref).max()
+
+
 def test_tiny_unet_compel_cfg_matches_reference(tiny):
     cfg = O.TINY_UNET
     sd = O.synth_state_dict(O.unet_param_shapes(cfg), seed=11)
