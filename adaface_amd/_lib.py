@@ -95,6 +95,7 @@ _SIGS = [
     ("af_rowpanel_launches", C.c_int64, []),
     ("af_up_phase4_launches", C.c_int64, []),
     ("af_gn_producer_launches", C.c_int64, []),
+    ("af_attn_short_launches", C.c_int64, []),
     ("af_op_conv2d_fp8", C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 10 + [_P]),
     ("af_op_groupnorm_fp8", C.c_int, [_P, _P, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("af_op_layernorm_fp8", C.c_int, [_P, _P, _P, C.c_float, _P, C.c_int64, C.c_int, C.c_int, _P]),
@@ -153,6 +154,7 @@ def plan_counts(reset: bool = False) -> dict:
     out["rowpanel"] = int(lib.af_rowpanel_launches())
     out["up_phase4"] = int(lib.af_up_phase4_launches())
     out["gn_producer"] = int(lib.af_gn_producer_launches())
+    out["attn_short"] = int(lib.af_attn_short_launches())
     if reset:
         lib.af_gemm_plan_counts_reset()
     return out

@@ -657,6 +657,172 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 }
 }  // namespace ring40
 
+// ---------------------------------------------------------------------------------------------------------------
+// Cross-attention over a SHORT key list (the 77 context tokens; S <= 96), bf16, dh = 40 / 80 (the 64x64 and 32x32 levels).
+//
+// The flash kernels above spend a cross-attention launch in their prologue: per workgroup they stage two 64-key tiles,
+// write pads, pass barriers and then run two tile iterations for 128-256 queries -- 43 / 28 us per launch for 0.4 GFLOP
+// per sample against 42 / 21 MB of Q + O traffic (8 / 4 us at HBM speed).  With S <= 96 the whole K and V of a (sample,
+// head) are 9-15 + 12-18 MFMA operand fragments: a wave keeps them in REGISTERS for its whole life and loops over blocks
+// of 32 queries with no LDS and no barrier at all:
+//     Q block (16-byte fragment loads, next block prefetched) -> S^T = K Q^T (3 key blocks) -> exact softmax over the <= 96
+//     scores a lane holds (one cross-half maximum) -> P fed back as the B operand (accumulator-as-operand) ->
+//     O^T = V^T P^T with the ones row giving the denominator -> 8-byte stores.
+//   * K fragments come straight from the cached [B][S][2C] K|V tensor (lane = key, 16 bytes of the head's channels);
+//   * V^T fragments come from a per-layer PACKED copy made once per af_set_context (pack_vt_kernel): element j of lane
+//     (d, half h) of k-step s is V[key = 16 s + 8 (j >> 2) + 4 h + (j & 3)][d] -- the key order in which the S^T accumulator
+//     comes back as an operand -- with row d = dh holding 1.0 (softmax denominator) and the other pad rows 0;
+//   * a workgroup = 4 waves = 4 heads of one sample (neighbouring 80 / 160-byte slices of the same Q rows).
+// ---------------------------------------------------------------------------------------------------------------
+namespace xs {
+constexpr int NKB = 3, SMAX = 32 * NKB;            // key blocks of 32; keys >= Nk are masked
+template <int DH> struct Cfg {
+  static constexpr int KS = (DH + 15) / 16;        // 16-wide k steps of QK^T (dh 40: 3, the last half zero)
+  static constexpr int DB = (DH + 1 + 31) / 32;    // 32-row blocks of O^T including the ones row
+  static constexpr int VSTEPS = 2 * NKB;           // 16-key k steps of PV
+  static constexpr long PACK_ELEMS_PER_HEAD = (long)DB * VSTEPS * 2 * 32 * 8;
+};
+
+// vt[b][head][db][ks][h][l31][8]
+template <int DH>
+__global__ __launch_bounds__(256) void pack_vt_kernel(const bf16* __restrict__ v, int ldv, long bsv, int Nk, int H, int B,
+                                                      bf16* __restrict__ vt) {
+  using C = Cfg<DH>;
+  const long total = (long)B * H * C::PACK_ELEMS_PER_HEAD;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i;
+    const int j = (int)(r & 7); r >>= 3;
+    const int l31 = (int)(r & 31); r >>= 5;
+    const int h = (int)(r & 1); r >>= 1;
+    const int ks = (int)(r % C::VSTEPS); r /= C::VSTEPS;
+    const int db = (int)(r % C::DB); r /= C::DB;
+    const int head = (int)(r % H);
+    const int b = (int)(r / H);
+    const int d = db * 32 + l31;
+    const int key = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+    float val = 0.f;
+    if (d < DH) { if (key < Nk) val = (float)v[(long)b * bsv + (long)key * ldv + head * DH + d]; }
+    else if (d == DH) val = 1.0f;
+    vt[i] = (bf16)val;
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void xattn_short_kernel(const AttnParams p, const bf16* __restrict__ vt, int bpw) {
+  using C = Cfg<DH>;
+  typedef bf16 T;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y * 4 + wave, b = blockIdx.z;
+  if (head >= p.H) return;                                          // (wave-uniform; no barrier in this kernel)
+  const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * p.bsq + head * DH;
+  const T* K = reinterpret_cast<const T*>(p.k) + (long)b * p.bsk + head * DH;
+  T* O = reinterpret_cast<T*>(p.o) + (long)b * p.bso + head * DH;
+  const float sl2 = p.scale * 1.44269504088896340736f;
+
+  // ---- resident operand fragments ----
+  uint4 kf[NKB][C::KS];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) {
+      const int key = 32 * kb + l31, d0 = 16 * s + 8 * h;
+      kf[kb][s] = make_uint4(0, 0, 0, 0);
+      if (key < p.Nk && d0 < DH) kf[kb][s] = *reinterpret_cast<const uint4*>(K + (long)key * p.ldk + d0);
+    }
+  uint4 vf[C::DB][C::VSTEPS];
+  {
+    const uint4* vp = reinterpret_cast<const uint4*>(vt + ((long)b * p.H + head) * C::PACK_ELEMS_PER_HEAD);
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+      for (int ks = 0; ks < C::VSTEPS; ++ks) vf[db][ks] = vp[((db * C::VSTEPS + ks) * 2 + h) * 32 + l31];
+  }
+  auto load_q = [&](int blk, uint4 (&qf)[C::KS]) {
+    const int q = blk * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) {
+      const int d0 = 16 * s + 8 * h;
+      qf[s] = make_uint4(0, 0, 0, 0);
+      if (q < p.Nq && d0 < DH) qf[s] = *reinterpret_cast<const uint4*>(Q + (long)q * p.ldq + d0);
+    }
+  };
+  const int nblk = (p.Nq + 31) / 32;
+  const int blk0 = blockIdx.x * bpw, blk1 = blk0 + bpw < nblk ? blk0 + bpw : nblk;
+  if (blk0 >= nblk) return;
+  uint4 qn[C::KS];
+  load_q(blk0, qn);
+  for (int blk = blk0; blk < blk1; ++blk) {
+    uint4 qf[C::KS];
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) {   // pre-scale by scale * log2(e): softmax is then exp2(s - m)
+      Vec16<T> v;
+      v.u = qn[s];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v.e[e] = from_f32<T>(to_f32<T>(v.e[e]) * sl2);
+      qf[s] = v.u;
+    }
+    if (blk + 1 < blk1) load_q(blk + 1, qn);
+    // ---- S^T = K Q^T ----
+    f32x16 sc[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < C::KS; ++s) Mma<T>::step(kf[kb][s], qf[s], sc[kb]);
+    }
+    // ---- exact softmax over the keys < Nk this lane's query column holds (rows split over the two lane halves) ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (32 * kb + acc_row(r, h) >= p.Nk) sc[kb][r] = -INFINITY;
+        mx = fmaxf(mx, sc[kb][r]);
+      }
+    mx = xhalf_max(mx);
+    uint4 pb[NKB][2];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        Vec16<T> v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v.e[j] = from_f32<T>(__builtin_amdgcn_exp2f(sc[kb][8 * s2 + j] - mx));
+        pb[kb][s2] = v.u;
+      }
+    // ---- O^T = V^T P^T (row DH = the softmax denominator) ----
+    f32x16 o[C::DB];
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) Mma<T>::step(vf[db][2 * kb + s2], pb[kb][s2], o[db]);
+    }
+    constexpr int rr = DH % 32, ob = DH / 32, oreg = (rr & 3) + 4 * (rr >> 3), oh = (rr >> 2) & 1;
+    const float l_tot = __shfl(o[ob][oreg], l31 + 32 * oh, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = blk * 32 + l31;
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = 32 * db + 8 * g + 4 * h;
+        if (dd < DH) {
+          Quad<T> ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov.e[e] = from_f32<T>(o[db][4 * g + e] * inv);
+          if (q < p.Nq) ov.store(O + (long)q * p.ldo + dd);
+        }
+      }
+  }
+}
+}  // namespace xs
+
 template <typename T, int DH> __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) { attn_body<T, DH>(p); }
 // dh = 40 (the 64x64 self-attention, 16 % of a denoising step): 132 VGPRs as written; capped at 128 the kernel runs
 // four waves per SIMD instead of three (LDS allows four workgroups per CU)
@@ -688,6 +854,47 @@ template <typename T, int DH> static int launch_attn(const AttnParams& p, int B,
   return 0;
 }
 
+// packed V^T fragments for xs::xattn_short_kernel (elements; 0 = this (dtype, dh, Nk) has no short-key kernel)
+template <typename T> long af_attn_short_pack_elems(int B, int H, int dh, int Nk) {
+  if (sizeof(T) != 2 || Nk <= 0 || Nk > xs::SMAX) return 0;
+  if (dh == 40) return (long)B * H * xs::Cfg<40>::PACK_ELEMS_PER_HEAD;
+  if (dh == 80) return (long)B * H * xs::Cfg<80>::PACK_ELEMS_PER_HEAD;
+  return 0;
+}
+template <typename T>
+int af_launch_attn_short_pack(const void* v, int ldv, long bsv, int Nk, int H, int dh, int B, void* vt, hipStream_t stream) {
+  if constexpr (sizeof(T) == 2) {
+    const long total = af_attn_short_pack_elems<T>(B, H, dh, Nk);
+    if (total <= 0) { af_set_error_msg("attention: no short-key pack for dh %d, %d keys", dh, Nk); return -1; }
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (dh == 40)
+      hipLaunchKernelGGL((xs::pack_vt_kernel<40>), dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const bf16*>(v), ldv, bsv, Nk, H, B, reinterpret_cast<bf16*>(vt));
+    else
+      hipLaunchKernelGGL((xs::pack_vt_kernel<80>), dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const bf16*>(v), ldv, bsv, Nk, H, B, reinterpret_cast<bf16*>(vt));
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  } else {
+    af_set_error_msg("attention: the short-key kernel is bf16 only");
+    return -1;
+  }
+}
+long g_af_attn_short_launches = 0;
+
+template <int DH> static int launch_xattn_short(const AttnParams& p, int B, hipStream_t stream) {
+  const int nblk = (p.Nq + 31) / 32;
+  // blocks of 32 queries per wave: enough waves to cover the chip twice (1024 SIMDs), at most 8 blocks each
+  const long wave_blocks = (long)B * p.H * nblk;
+  int bpw = (int)(wave_blocks / 2048);
+  if (bpw < 1) bpw = 1;
+  if (bpw > 8) bpw = 8;
+  dim3 grid((nblk + bpw - 1) / bpw, (p.H + 3) / 4, B);
+  hipLaunchKernelGGL((xs::xattn_short_kernel<DH>), grid, dim3(256), 0, stream, p, reinterpret_cast<const bf16*>(p.vt_pack), bpw);
+  HIP_CHECK_RET(hipGetLastError());
+  ++g_af_attn_short_launches;
+  return 0;
+}
+
 template <typename T> int af_launch_attention(const AttnParams& p, int B, int dh, hipStream_t stream) {
   constexpr int EPC = 16 / sizeof(T);
   if (p.ldq % EPC || p.ldk % EPC || p.ldv % EPC || p.ldo % 4 || p.Nk <= 0) {
@@ -697,6 +904,11 @@ template <typename T> int af_launch_attention(const AttnParams& p, int B, int dh
   if (p.Nq <= 0 || B <= 0) return 0;
   AfProfScope prof(AF_K_ATTENTION, stream, 4.0 * B * p.H * (double)p.Nq * p.Nk * dh,
                    (2.0 * p.Nq + 2.0 * p.Nk) * B * p.H * dh * sizeof(T));
+  if constexpr (sizeof(T) == 2) {
+    // short key list with the V^T fragments packed by the caller: the register-resident cross-attention kernel
+    if (p.vt_pack && g_af_knobs.attn_short && !p.causal && !p.lse && p.Nk <= xs::SMAX && (dh == 40 || dh == 80))
+      return dh == 40 ? launch_xattn_short<40>(p, B, stream) : launch_xattn_short<80>(p, B, stream);
+  }
   switch (dh) {
     case 8: return launch_attn<T, 8>(p, B, stream);
     case 16: return launch_attn<T, 16>(p, B, stream);
@@ -713,4 +925,8 @@ template <typename T> int af_launch_attention(const AttnParams& p, int B, int dh
 }
 
 template int af_launch_attention<bf16>(const AttnParams&, int, int, hipStream_t);
+template long af_attn_short_pack_elems<bf16>(int, int, int, int);
+template long af_attn_short_pack_elems<float>(int, int, int, int);
+template int af_launch_attn_short_pack<bf16>(const void*, int, long, int, int, int, int, void*, hipStream_t);
+template int af_launch_attn_short_pack<float>(const void*, int, long, int, int, int, int, void*, hipStream_t);
 template int af_launch_attention<float>(const AttnParams&, int, int, hipStream_t);

@@ -97,6 +97,7 @@ struct AfKnobs {
   int conv_up_phase4;       // AF_CONV_UP_PHASE4       0 = upsampled 3x3 convolutions gather all nine taps from the upsampled map
   int pp_sched;             // AF_PP_SCHED             eight-wave kernel: 0 = round-1 compute phase (two K halves, a full LDS drain
                             //                         after each), 1 = block-ordered compute phase, 2 = merged (no staging phase)
+  int attn_short;           // AF_ATTN_SHORT           0 = cross-attention (<= 96 keys) stays on the flash kernels
 };
 extern AfKnobs g_af_knobs;
 
@@ -322,4 +323,6 @@ struct AttnParams {
   float scale;
   float* lse;   // optional [B][H][Nq]: log2-domain log-sum-exp of the scaled scores (m + log2 l); null = off
   int causal;   // != 0: query i attends to keys <= i only (the CLIP text tower's mask, modeling_clip causal mask)
+  const void* vt_pack;   // bf16, optional: V packed as resident MFMA fragments (af_launch_attn_short_pack) -> the short-key
+                         // cross-attention kernel runs when Nk <= 96 and dh is 40 or 80; null = the flash kernels
 };

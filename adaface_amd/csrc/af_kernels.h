@@ -7,6 +7,12 @@ template <typename T>
 int af_launch_conv_gemm(const ConvGemmParams& p, int batch, hipStream_t stream, const AfGemmPlan* plan = nullptr,
                         void* ws = nullptr);
 template <typename T> int af_launch_attention(const AttnParams& p, int B, int dh, hipStream_t stream);
+// V packed as the resident MFMA fragments of the short-key cross-attention kernel (bf16; Nk <= 96, dh 40 / 80): elements
+// needed (0 = no such kernel for this case) and the pack launch; AttnParams::vt_pack then selects the kernel
+template <typename T> long af_attn_short_pack_elems(int B, int H, int dh, int Nk);
+template <typename T>
+int af_launch_attn_short_pack(const void* v, int ldv, long bsv, int Nk, int H, int dh, int B, void* vt, hipStream_t stream);
+extern long g_af_attn_short_launches;
 
 size_t af_gn_workspace_bytes(int B, int HW);
 template <typename T>

@@ -54,7 +54,7 @@ AfKnobs g_af_knobs = {
     knob_env("AF_GN_SMALL", 1),        knob_env("AF_GN_FOLD", 1),         knob_env("AF_CONV_TAP_INNER", 1),
     knob_env("AF_LN_FUSE", 1),         knob_env("AF_GEGLU_ROWPANEL", 4), knob_env("AF_CONV_HALO8", 1), knob_env("AF_CONV_FAST_TAPS", 1),
     knob_env("AF_PP_STAGGER", 1),      knob_env("AF_GN_PRODUCER", 1),     knob_env("AF_CONV_UP_PHASE4", 1),
-    knob_env("AF_PP_SCHED", 2)};
+    knob_env("AF_PP_SCHED", 2),        knob_env("AF_ATTN_SHORT", 1)};
 static const AfKnobs g_af_knobs_initial = g_af_knobs;
 static int* knob_slot(const char* name) {
   static const struct { const char* n; int AfKnobs::*m; } tab[] = {
@@ -63,7 +63,8 @@ static int* knob_slot(const char* name) {
       {"gemm_tile", &AfKnobs::gemm_tile}, {"gemm_splitk", &AfKnobs::gemm_splitk}, {"gemm_groupm", &AfKnobs::gemm_groupm},
       {"gemm_dma", &AfKnobs::gemm_dma}, {"pp_direct", &AfKnobs::pp_direct}, {"attn_w4", &AfKnobs::attn_w4}, {"attn_ring", &AfKnobs::attn_ring},
       {"gn_small", &AfKnobs::gn_small}, {"gn_fold", &AfKnobs::gn_fold}, {"conv_tap_inner", &AfKnobs::conv_tap_inner}, {"ln_fuse", &AfKnobs::ln_fuse},
-      {"geglu_rowpanel", &AfKnobs::geglu_rowpanel}, {"conv_halo8", &AfKnobs::conv_halo8}, {"conv_fast_taps", &AfKnobs::conv_fast_taps}, {"pp_stagger", &AfKnobs::pp_stagger}, {"gn_producer", &AfKnobs::gn_producer}, {"conv_up_phase4", &AfKnobs::conv_up_phase4}, {"pp_sched", &AfKnobs::pp_sched}};
+      {"geglu_rowpanel", &AfKnobs::geglu_rowpanel}, {"conv_halo8", &AfKnobs::conv_halo8}, {"conv_fast_taps", &AfKnobs::conv_fast_taps}, {"pp_stagger", &AfKnobs::pp_stagger}, {"gn_producer", &AfKnobs::gn_producer}, {"conv_up_phase4", &AfKnobs::conv_up_phase4}, {"pp_sched", &AfKnobs::pp_sched},
+      {"attn_short", &AfKnobs::attn_short}};
   if (!name) return nullptr;
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) return &(g_af_knobs.*(t.m));
@@ -227,6 +228,8 @@ struct Slot {  // one expected state_dict tensor
 struct CtxKV {  // cached cross-attention K/V for one transformer block
   void* kv = nullptr;  // [Bf*n_tokens][2*C]
   int C = 0;
+  void* vt = nullptr;   // V packed as the resident fragments of the short-key cross-attention kernel (bf16, dh 40 / 80), or null
+  size_t vt_bytes = 0;
 };
 
 struct af_handle {
@@ -939,7 +942,8 @@ struct Runner {
   }
   // samples [b0, b0 + nb) of the batch (nb < 0: all of o.B); lse: optional [nb][heads][Nq] log-sum-exp output
   int attention(const void* q, int ldq, long bsq, const void* k, int ldk, long bsk, const void* v, int ldv, long bsv,
-                Act& o, int Nq, int Nk, int heads, int dh, int b0 = 0, int nb = -1, float* lse = nullptr, int causal = 0) {
+                Act& o, int Nq, int Nk, int heads, int dh, int b0 = 0, int nb = -1, float* lse = nullptr, int causal = 0,
+                const void* vt_pack = nullptr, size_t vt_sample_bytes = 0) {
     AF_TRY(check(o));
     if (dry) return 0;
     if (nb < 0) nb = o.B;
@@ -952,6 +956,7 @@ struct Runner {
     p.scale = 1.0f / sqrtf((float)dh);
     p.lse = lse;
     p.causal = causal;
+    p.vt_pack = vt_pack ? reinterpret_cast<const char*>(vt_pack) + (size_t)b0 * vt_sample_bytes : nullptr;
     return DISPATCH(dt, af_launch_attention<bf16>(p, nb, dh, s), af_launch_attention<float>(p, nb, dh, s));
   }
   int copy_channels(const Act& src, Act& dst, int off) {
@@ -1126,7 +1131,7 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out, bool twin
     const bool conv_attn = h->conv_ks >= 2 && !h->conv_batch.empty() && !(ca_layer >= 6 && ca_layer <= 10);
     if (!conv_attn) {
       AF_TRY(R.attention(q.p, C, (long)N * C, kv.kv, 2 * C, (long)S * 2 * C, R.dry ? nullptr : R.elem_ptr(kv.kv, C),
-                         2 * C, (long)S * 2 * C, a, N, S, w.heads, w.dh));
+                         2 * C, (long)S * 2 * C, a, N, S, w.heads, w.dh, 0, -1, nullptr, 0, kv.vt, B > 0 ? kv.vt_bytes / (size_t)B : 0));
     } else {
       // runs of consecutive samples with / without the subject: flash attention over all S keys, or over the first
       // S-ks^2 (the subject's keys were moved to the end by af_set_context) followed by the exact softmax merge with
@@ -1768,7 +1773,7 @@ void af_destroy(af_handle* h) {
   hipSetDevice(h->device);
   hipDeviceSynchronize();
   for (void* p : h->owned) hipFree(p);
-  for (auto& kv : h->ctx_kv) if (kv.kv) hipFree(kv.kv);
+  for (auto& kv : h->ctx_kv) { if (kv.kv) hipFree(kv.kv); if (kv.vt) hipFree(kv.vt); }
   if (h->ctx_rowmap) hipFree(h->ctx_rowmap);
   if (h->ctx_cast) hipFree(h->ctx_cast);
   if (h->arena.base) hipFree(h->arena.base);
@@ -1903,6 +1908,14 @@ int af_set_context(af_handle* h, const float* ctx_dev, int Bf, int n_tokens, int
       h->ctx_kv[i].C = C;
       h->ctx_kv[i].kv = nullptr;
       HIP_CHECK_RET(hipMalloc(&h->ctx_kv[i].kv, (size_t)Bf * n_tokens * 2 * C * esize(dt)));
+      if (h->ctx_kv[i].vt) hipFree(h->ctx_kv[i].vt);
+      h->ctx_kv[i].vt = nullptr;
+      h->ctx_kv[i].vt_bytes = 0;
+      const long pe = dt == AF_DTYPE_BF16 ? af_attn_short_pack_elems<bf16>(Bf, x.heads, x.dh, n_tokens) : 0;
+      if (pe > 0) {
+        HIP_CHECK_RET(hipMalloc(&h->ctx_kv[i].vt, (size_t)pe * 2));
+        h->ctx_kv[i].vt_bytes = (size_t)pe * 2;
+      }
     }
   }
   if (h->conv_ks >= 2 && !h->conv_batch.empty()) {
@@ -1971,6 +1984,9 @@ int af_set_context(af_handle* h, const float* ctx_dev, int Bf, int n_tokens, int
     p.M = Bf * n_tokens; p.N = 2 * C; p.K = D;
     p.out = h->ctx_kv[i].kv; p.ldo = 2 * C; p.alpha = 1.0f;
     AF_TRY(DISPATCH(dt, af_launch_conv_gemm<bf16>(p, 1, s), af_launch_conv_gemm<float>(p, 1, s)));
+    if (h->ctx_kv[i].vt)   // V of this layer as resident fragments (rows of the key list as they now stand)
+      AF_TRY(af_launch_attn_short_pack<bf16>(reinterpret_cast<char*>(h->ctx_kv[i].kv) + (size_t)C * 2, 2 * C, (long)n_tokens * 2 * C,
+                                             n_tokens, x.heads, x.dh, Bf, h->ctx_kv[i].vt, s));
   }
   h->ctx_Bf = Bf;
   h->ctx_tokens = n_tokens;
@@ -2205,6 +2221,7 @@ int af_gemm_plan_counts(int64_t* counts10) {
   return AF_OK;
 }
 int af_gemm_plan_counts_reset(void) {
+  g_af_attn_short_launches = 0;
   for (int i = 0; i < 15; ++i) g_af_plan_counts[i] = 0;
   return AF_OK;
 }
@@ -2213,6 +2230,7 @@ int64_t af_halo8_launches(void) { return g_af_plan_counts[11]; }
 int64_t af_rowpanel_launches(void) { return g_af_plan_counts[12]; }
 int64_t af_up_phase4_launches(void) { return g_af_plan_counts[13]; }
 int64_t af_gn_producer_launches(void) { return g_af_plan_counts[14]; }
+int64_t af_attn_short_launches(void) { return g_af_attn_short_launches; }
 int af_set_fp8(af_handle* h, int on) {
   if (!h) { af_set_error_msg("af_set_fp8: null handle"); return AF_ERR_INVALID; }
   if (on && h->dtype != AF_DTYPE_BF16) { af_set_error_msg("af_set_fp8: the fp8 convolutions extend the bf16 mode (handle is f32)"); return AF_ERR_STATE; }

@@ -412,6 +412,15 @@ int af_op_attention(int dtype, const float* q_dev, const float* k_dev, const flo
   p.ldq = p.ldk = p.ldv = p.ldo = C;
   p.bsq = (long)Nq * C; p.bso = (long)Nq * C; p.bsk = (long)Nk * C; p.bsv = (long)Nk * C;
   p.Nq = Nq; p.Nk = Nk; p.H = heads; p.scale = scale;
+  p.vt_pack = nullptr;
+  if (dtype == AF_DTYPE_BF16 && !causal) {   // as af_set_context does for the cached cross-attention K / V
+    const long pe = af_attn_short_pack_elems<bf16>(B, heads, dh, Nk);
+    if (pe > 0) {
+      OP_ALLOC(vt, (size_t)pe * 2, false);
+      OP_TRY(af_launch_attn_short_pack<bf16>(vn, C, (long)Nk * C, Nk, heads, dh, B, vt, s));
+      p.vt_pack = vt;
+    }
+  }
   OP_TRY(DISP(dtype, af_launch_attention<bf16>(p, B, dh, s), af_launch_attention<float>(p, B, dh, s)));
   OP_TRY(DISP(dtype, af_launch_cast_to_f32<bf16>(on, o_dev, nq, s), af_launch_cast_to_f32<float>(on, o_dev, nq, s)));
   return 0;

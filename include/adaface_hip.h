@@ -239,6 +239,9 @@ int af_set_fp8(af_handle* h, int on);
 int64_t af_fp8_gemm_launches(void); /* launches on the fp8 kernel since af_gemm_plan_counts_reset */
 int64_t af_halo8_launches(void);    /* launches of the eight-wave LDS-halo 3x3 kernel (also counted under tile 5) */
 int64_t af_gn_producer_launches(void); /* convolutions that also wrote the GroupNorm partial sums of their output (no statistics pass in the consumer) */
+/* launches of the register-resident short-key cross-attention kernel (bf16, <= 96 keys, dh 40 / 80) since the last
+ * af_gemm_plan_counts_reset */
+int64_t af_attn_short_launches(void);
 int64_t af_up_phase4_launches(void); /* upsampled 3x3 convolutions run as four 2x2 phase convolutions on the stored map */
 int64_t af_rowpanel_launches(void); /* launches of the row-panel kernels (K = 320 / 640 / 1280 GEMMs with the activation rows resident in registers) */
 int af_op_conv2d_fp8(const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev, float* y_dev,

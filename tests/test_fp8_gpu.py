@@ -137,7 +137,7 @@ def test_layernorm_fp8_output(gpu, report, rows, C):
     assert torch.isfinite(got).all() and excess <= 0.0, excess
 
 
-def test_fp8_outlier_channels_saturate_at_56(gpu, report):
+def test_fp8_outlier_channels_saturate_at_56(gpu, report, knobs):
     """VERDICT r2 weak #3 / ADVICE: the fp8 mode writes GroupNorm + SiLU outputs as e4m3 of value * 2^3, so anything beyond
     +-448 / 8 = +-56 SATURATES (the fixed activation scale; gn_pack4_e4m3 clamps, there is no per-tensor rescale).  The
     synthetic benchmark weights never get there; a checkpoint with outlier channels can.  Heavy-tailed input: six
@@ -151,6 +151,7 @@ def test_fp8_outlier_channels_saturate_at_56(gpu, report):
           error of the unclipped part -- finite and local, not a blow-up.
     The reference has no fp8 path: config 4's arithmetic is PARITY UNPINNED; this test pins the saturation behaviour only."""
     from adaface_amd import ops
+    knobs("gemm_pp_minfill", 0)                 # M = 2048 would not fill half the chip: force the fp8 plan (as the kernel tests)
     g = torch.Generator().manual_seed(99)
     B, C, H, W, Cout = 2, 320, 32, 32, 320
     x = torch.randn(B, C, H, W, generator=g)

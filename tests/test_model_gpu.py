@@ -352,6 +352,8 @@ def test_sd15_unet_batch_consistency(gpu, report):
             assert pc["up_phase4"] == 3 and pc["rowpanel"] >= 35, pc
             # ResBlock convolutions at the 64x64 / 32x32 levels that also summed the GroupNorm statistics of their output
             assert pc["gn_producer"] >= 15, pc
+            # the ten cross-attention layers of the 64x64 / 32x32 levels on the register-resident short-key kernel
+            assert pc["attn_short"] == 10, pc
             e16 = (eps16 - eps_f32).abs().max().item() / eps_f32.abs().max().item()
             report("sd15_unet Bf=16 bf16 forward vs f32-mode forward of the same batch", e16, eps_f32.abs().max().item(), BF16_FWD_BAR)
             assert e16 <= BF16_FWD_BAR, e16

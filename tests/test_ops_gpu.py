@@ -547,6 +547,38 @@ def test_attention_dh40_ring_shapes(gpu, report, B, Nq, Nk, heads):
     _cmp(report, f"attention ring N{Nq} S{Nk} h{heads} d40", got, ref, "bf16")
 
 
+@pytest.mark.parametrize("B,Nq,Nk,heads,dh", [
+    (2, 4096, 77, 8, 40),      # the 64x64-level cross-attention: 8 query blocks per wave
+    (3, 1024, 77, 8, 80),      # the 32x32 level
+    (1, 1000, 77, 8, 40),      # ragged last query block (1000 = 31 * 32 + 8)
+    (2, 96, 96, 5, 40),        # a full key list, a partial head group (heads 4 of 5 and 1 of 5 in two workgroups)
+    (1, 33, 1, 4, 80),         # one key: softmax weight 1
+    (2, 256, 68, 8, 80),       # conv attention leaves S - 9 keys to the flash part; 68 keys here on the short kernel
+    (1, 64, 33, 8, 40),        # one key in the second key block
+])
+def test_attention_short_keys_register_resident(gpu, report, knobs, B, Nq, Nk, heads, dh):
+    """xs::xattn_short_kernel (cross-attention over <= 96 keys with K / V^T fragments resident in registers) against
+    torch, and against the flash kernel it replaces on the same inputs (knob attn_short = 0); the launch counter proves
+    which one ran."""
+    from adaface_amd import _lib, ops
+    g = torch.Generator().manual_seed(Nq + 3 * Nk + dh)
+    C = heads * dh
+    q = _q(torch.randn(B, Nq, C, generator=g), "bf16")
+    k = _q(torch.randn(B, Nk, C, generator=g), "bf16")
+    v = _q(torch.randn(B, Nk, C, generator=g) * 1.5 + 0.2, "bf16")
+    ref = _ref_attention(q, k, v, heads)
+    _lib.plan_counts(reset=True)
+    got = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), heads, dtype="bf16", nan_guard=True)
+    assert _lib.plan_counts(reset=True)["attn_short"] == 1
+    _cmp(report, f"attention short-key N{Nq} S{Nk} h{heads} d{dh}", got, ref, "bf16")
+    knobs("attn_short", 0)
+    flash = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), heads, dtype="bf16")
+    assert _lib.plan_counts(reset=True)["attn_short"] == 0
+    d = (got - flash).abs().max().item()
+    report(f"attention short-key vs flash kernel N{Nq} S{Nk} d{dh}[bf16]", d, ref.abs().max().item(), 2 * TOL["bf16"] * ref.abs().max().item())
+    assert d <= 2 * TOL["bf16"] * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("Nk", [77, 129])
 def test_attention_dh40_ring_nan_guard(gpu, report, Nk):
     """the ring kernel zero-fills rows >= Nk of the last key tile through the buffer range check.  K and V are
