@@ -96,6 +96,7 @@ _SIGS = [
     ("af_up_phase4_launches", C.c_int64, []),
     ("af_gn_producer_launches", C.c_int64, []),
     ("af_attn_short_launches", C.c_int64, []),
+    ("af_gn_consumer_launches", C.c_int64, []),
     ("af_op_conv2d_fp8", C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 10 + [_P]),
     ("af_op_groupnorm_fp8", C.c_int, [_P, _P, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("af_op_layernorm_fp8", C.c_int, [_P, _P, _P, C.c_float, _P, C.c_int64, C.c_int, C.c_int, _P]),
@@ -105,6 +106,7 @@ _SIGS = [
     ("af_clip_text_forward", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P]),
     ("af_clip_text_forward3", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P, _P]),
     ("af_op_timestep_embedding", C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P]),
+    ("af_op_gn_conv1x1", C.c_int, [_P, _P, _P, C.c_float, _P, _P, _P, _P] + [C.c_int] * 5 + [_P]),
     ("af_flops_issued", C.c_double, [C.c_int]),
     ("af_clock_probe", C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 ]
@@ -155,6 +157,7 @@ def plan_counts(reset: bool = False) -> dict:
     out["up_phase4"] = int(lib.af_up_phase4_launches())
     out["gn_producer"] = int(lib.af_gn_producer_launches())
     out["attn_short"] = int(lib.af_attn_short_launches())
+    out["gn_consumer"] = int(lib.af_gn_consumer_launches())
     if reset:
         lib.af_gemm_plan_counts_reset()
     return out

@@ -98,6 +98,8 @@ struct AfKnobs {
   int pp_sched;             // AF_PP_SCHED             eight-wave kernel: 0 = round-1 compute phase (two K halves, a full LDS drain
                             //                         after each), 1 = block-ordered compute phase, 2 = merged (no staging phase)
   int attn_short;           // AF_ATTN_SHORT           0 = cross-attention (<= 96 keys) stays on the flash kernels
+  int gn_consumer;          // AF_GN_CONSUMER          0 = the SpatialTransformer's GroupNorm always runs its own apply pass (never
+                            //                         in the prologue of a row-panel proj_in)
 };
 extern AfKnobs g_af_knobs;
 
@@ -305,6 +307,12 @@ struct ConvGemmParams {
   // npart = Ho * Wo / 64 (fixed order, no atomics).  The consumer GroupNorm then needs no statistics pass over the tensor.
   float* gn_stats_out;
   int gn_cpg;
+  // GroupNorm applied by the CONSUMER (row-panel kernels only: their activation rows sit in registers for the whole launch):
+  // src holds the UN-normalised x, gn_ab [B][2][K] the per-sample scale / shift (af_launch_groupnorm_fold), gn_hw the rows
+  // per sample (a multiple of the panel height); the prologue replaces x by bf16(fma(x, a, b)) -- the value gn_apply_kernel
+  // would have stored
+  const float* gn_ab;
+  int gn_hw;
 };
 
 struct AfGemmPlan {

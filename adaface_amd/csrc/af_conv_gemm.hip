@@ -1672,6 +1672,26 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
 #pragma unroll
       for (int u = 0; u < 2; ++u)
         xr[j][kc][u] = __builtin_bit_cast(pp_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xo, (kc * 64 + u * 32) * 2, 0));
+    if (p.gn_ab) {
+      // GroupNorm of the consumer's input (see ConvGemmParams::gn_ab): the panel lies inside one sample
+      const float* ga = p.gn_ab + (long)(m0 / p.gn_hw) * 2 * C::K + 8 * (lane >> 4);
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float* gp = ga + kc * 64 + u * 32;
+          float sc[8], sh[8];
+          *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(gp);
+          *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(gp + 4);
+          *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(gp + C::K);
+          *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(gp + C::K + 4);
+          Vec16<T> v;
+          v.u = __builtin_bit_cast(uint4, xr[j][kc][u]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v.e[e] = from_f32<T>(fmaf(to_f32<T>(v.e[e]), sc[e], sh[e]));
+          xr[j][kc][u] = __builtin_bit_cast(pp_u32x4, v.u);
+        }
+    }
     if constexpr (LNMODE == 1) {
       float2 st = float2{0.f, 0.f};
       if (ok && p.ln_parts_n > 0) {
@@ -1938,7 +1958,9 @@ static int launch_plain_rowpanel_k1280(const ConvGemmParams& p, hipStream_t stre
 }
 static int launch_plain_rowpanel(const ConvGemmParams& p, hipStream_t stream, bool k640 = false) {
   const bool res = p.residual != nullptr;
-  if (k640) {   // (at K = 640 only the LayerNorm-consumer q / k / v projection is long enough to gain)
+  if (k640) {   // (at K = 640 only the LayerNorm-consumer q / k / v projection is long enough to gain -- and proj_in when it
+                // applies the GroupNorm of its input itself: statistics-producer epilogue)
+    if (p.ln_stats_out) return launch_rowpanel_one<false, 2, false, 10, 1>(p, stream);
     return p.ln_stats ? launch_rowpanel_one<false, 1, false, 10, 1>(p, stream) : launch_rowpanel_one<false, 0, false, 10, 1>(p, stream);
   }
   if (p.ln_stats) return res ? launch_rowpanel_one<false, 1, true>(p, stream) : launch_rowpanel_one<false, 1, false>(p, stream);
@@ -2314,6 +2336,7 @@ int af_launch_cast_fp8(const void* x, void* y, long n, float mul, hipStream_t st
 }
 
 AfGemmPlan g_af_last_plan = {0, 1, 0, 0, 1};
+long g_af_gn_consumer_launches = 0;   // row-panel launches that applied the GroupNorm of their input themselves
 // launches since af_gemm_plan_counts_reset: [0..5] by tile (implicit-GEMM / ping-pong kernels), [6] LDS-halo kernel,
 // [7] launches that sliced K (counted in their tile's slot as well), [8] / [9] ping-pong launches with the LayerNorm
 // consumer / statistics-producer epilogue, [10] ping-pong launches with fp8 operands, [11] eight-wave halo launches
@@ -2740,14 +2763,22 @@ int af_conv_rowpanel_kind(const ConvGemmParams& p, int batch) {
       p.Cin != p.K || p.ldc < p.Cin)
     return 0;
   const bool geglu = p.epilogue == AF_EPI_GEGLU;
+  // (a consumer-side GroupNorm needs whole panels inside one sample: 256-row panels at K = 320, 128-row ones at K = 640)
   if (p.K == RowPanelCfg::K && p.M >= 128 * RowPanelCfg::BM) {
+    if (p.gn_ab && (p.gn_hw <= 0 || p.gn_hw % RowPanelCfg::BM != 0)) return 0;
     if (geglu) return (p.N % RowPanelCfg::BN == 0 && !p.residual && !p.ln_stats_out) ? 1 : 0;
     return (lvl >= 2 && p.N % 160 == 0 && p.alpha == 1.0f && !(p.ln_stats && p.ln_stats_out) && (!p.residual || p.ldr % 4 == 0)) ? 2 : 0;
   }
   if (p.K == 1280)
-    return (lvl >= 4 && p.N == 1280 && p.M >= 4096 && !geglu && p.alpha == 1.0f && !p.ln_stats && !p.ln_stats_out &&
+    return (lvl >= 4 && p.N == 1280 && p.M >= 4096 && !geglu && p.alpha == 1.0f && !p.ln_stats && !p.ln_stats_out && !p.gn_ab &&
             (!p.residual || p.ldr % 4 == 0)) ? 3 : 0;
-  if (p.K == 640 && lvl >= 3 && p.M >= 16384 && !p.residual && !p.ln_stats_out) {
+  if (p.K == 640 && lvl >= 3 && p.M >= 16384 && !p.residual) {
+    if (p.gn_ab) {
+      // proj_in of a 32x32-level transformer with its GroupNorm applied in the prologue: N = 640 is short for this kernel (the
+      // tiled one measures ahead on the bare GEMM), but the GroupNorm pass it saves is as long as the GEMM itself
+      return (!geglu && p.gn_hw > 0 && p.gn_hw % 128 == 0 && p.N % 160 == 0 && p.alpha == 1.0f && !p.ln_stats) ? 5 : 0;
+    }
+    if (p.ln_stats_out) return 0;
     if (geglu) return p.N % 128 == 0 ? 4 : 0;
     return (p.N % 160 == 0 && p.N >= 1920 && p.alpha == 1.0f) ? 5 : 0;
   }
@@ -2762,6 +2793,7 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
     if constexpr (sizeof(T) == 2) return batch == 1 ? launch_conv_gemm_fp8(p, stream, plan, ws) : (af_set_error_msg("conv_gemm fp8: no batched form"), -1);
     else { af_set_error_msg("conv_gemm: fp8 operands need the bf16 storage mode"); return -1; }
   }
+  if (p.gn_ab && sizeof(T) != 2) { af_set_error_msg("conv_gemm: consumer-side GroupNorm exists on the bf16 row-panel kernels only"); return -1; }
   if (p.K % BK != 0 || p.Cin % BK != 0 || p.K != p.ks * p.ks * p.Cin) {
     af_set_error_msg("conv_gemm: K=%d Cin=%d ks=%d must satisfy K==ks*ks*Cin and Cin%%%d==0", p.K, p.Cin, p.ks, BK);
     return -1;
@@ -2836,6 +2868,11 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
       af_set_error_msg("conv_gemm: un-finalised LayerNorm statistics handed to a launch that is not a row-panel one");
       return -1;
     }
+    if (p.gn_ab && !rk) {
+      af_set_error_msg("conv_gemm: consumer-side GroupNorm asked of a launch that is not a row-panel one (ask af_conv_rowpanel_kind first)");
+      return -1;
+    }
+    if (p.gn_ab) g_af_gn_consumer_launches += 1;
     if (rk) g_af_plan_counts[12] += 1;
     switch (rk) {
       case 1: return launch_geglu_rowpanel(p, stream);

@@ -20,6 +20,12 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
                         const float* beta, float eps, int silu, void* y, long y_bs, int ldy, void* workspace,
                         hipStream_t stream, float fp8_mul = 0.f,    // fp8_mul != 0: y is e4m3 bytes of result * fp8_mul
                         const float* pre_partial = nullptr, int pre_npart = 0);   // statistics already summed by the producer
+// GroupNorm reduced to its per-sample affine map ab_out [B][2][Cn] (scale, shift) for a consumer that applies it itself
+// (ConvGemmParams::gn_ab): statistics pass (unless pre_partial) + fold, no pass that writes the normalised tensor
+template <typename T>
+int af_launch_groupnorm_fold(const void* x, long x_bs, int ldx, int B, int HW, int Cn, const float* gamma, const float* beta,
+                             float eps, void* workspace, hipStream_t stream, const float* pre_partial, int pre_npart,
+                             float* ab_out);
 // would a bf16 convolution with these parameters on this plan write GroupNorm partial sums (ConvGemmParams::gn_stats_out)?
 bool af_conv_gn_stats_ok(const ConvGemmParams& p, const AfGemmPlan& pl, int cpg);
 int af_conv_rowpanel_kind(const ConvGemmParams& p, int batch);   // 0 = not a row-panel launch (p.splitk as planned)
@@ -84,6 +90,7 @@ int af_launch_ln_finalize(const float* part, int parts, int M, int count, float 
 // plan of the most recent af_launch_conv_gemm (diagnostics, af_last_gemm_plan)
 extern AfGemmPlan g_af_last_plan;
 extern long g_af_plan_counts[15];
+extern long g_af_gn_consumer_launches;
 int af_launch_up_phase4_weights(const void* w3, int rows, int cin, int ldw3, void* w4, hipStream_t stream);
 // fp8 (e4m3) twin of a repacked bf16 weight (K in 64-channel units, power-of-two row scales) / saturating bf16 -> e4m3 cast
 int af_launch_quant_weight_fp8(const void* w, int rows, int ldw, int cin_pad, int ks, void* w8, int k8, unsigned char* sc,

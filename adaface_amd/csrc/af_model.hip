@@ -54,7 +54,7 @@ AfKnobs g_af_knobs = {
     knob_env("AF_GN_SMALL", 1),        knob_env("AF_GN_FOLD", 1),         knob_env("AF_CONV_TAP_INNER", 1),
     knob_env("AF_LN_FUSE", 1),         knob_env("AF_GEGLU_ROWPANEL", 4), knob_env("AF_CONV_HALO8", 1), knob_env("AF_CONV_FAST_TAPS", 1),
     knob_env("AF_PP_STAGGER", 1),      knob_env("AF_GN_PRODUCER", 1),     knob_env("AF_CONV_UP_PHASE4", 1),
-    knob_env("AF_PP_SCHED", 2),        knob_env("AF_ATTN_SHORT", 1)};
+    knob_env("AF_PP_SCHED", 2),        knob_env("AF_ATTN_SHORT", 1),      knob_env("AF_GN_CONSUMER", 1)};
 static const AfKnobs g_af_knobs_initial = g_af_knobs;
 static int* knob_slot(const char* name) {
   static const struct { const char* n; int AfKnobs::*m; } tab[] = {
@@ -64,7 +64,7 @@ static int* knob_slot(const char* name) {
       {"gemm_dma", &AfKnobs::gemm_dma}, {"pp_direct", &AfKnobs::pp_direct}, {"attn_w4", &AfKnobs::attn_w4}, {"attn_ring", &AfKnobs::attn_ring},
       {"gn_small", &AfKnobs::gn_small}, {"gn_fold", &AfKnobs::gn_fold}, {"conv_tap_inner", &AfKnobs::conv_tap_inner}, {"ln_fuse", &AfKnobs::ln_fuse},
       {"geglu_rowpanel", &AfKnobs::geglu_rowpanel}, {"conv_halo8", &AfKnobs::conv_halo8}, {"conv_fast_taps", &AfKnobs::conv_fast_taps}, {"pp_stagger", &AfKnobs::pp_stagger}, {"gn_producer", &AfKnobs::gn_producer}, {"conv_up_phase4", &AfKnobs::conv_up_phase4}, {"pp_sched", &AfKnobs::pp_sched},
-      {"attn_short", &AfKnobs::attn_short}};
+      {"attn_short", &AfKnobs::attn_short}, {"gn_consumer", &AfKnobs::gn_consumer}};
   if (!name) return nullptr;
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) return &(g_af_knobs.*(t.m));
@@ -788,6 +788,9 @@ struct Runner {
     int parts_n = 0, count = 0;
     float eps = 0.f;
     float* stats_buf = nullptr;
+    // GroupNorm of the input applied by the (row-panel) GEMM itself: per-sample scale / shift, rows per sample
+    const float* gn_ab = nullptr;
+    int gn_hw = 0;
   };
   int ln_finalize(const float* part, int parts, long M, int count, float eps, float* out) {
     if (dry) return 0;
@@ -844,6 +847,29 @@ struct Runner {
     if (pl.tile < 4 || pl.splitk > 1 || pl.halo_tw) return 0;
     return (p.N / (pl.tile == 5 ? 160 : 128)) * 2;
   }
+  // would conv(L, x, out, ..., ln) be a row-panel launch (the only kernels that can apply a GroupNorm of their input)?
+  bool rowpanel_capable(const Linear& L, const Act& x, const Act& out, const LnArgs* ln, int gn_hw) const {
+    if (dt != AF_DTYPE_BF16 || L.ks != 1 || x.f8) return false;
+    ConvGemmParams p;
+    conv_params(p, L, x, out, 1, 0, nullptr, nullptr, 0, -1, -1);
+    if (ln) { p.ln_stats = ln->stats; p.ln_colsum = ln->colsum; p.ln_stats_out = ln->stats_out; }
+    p.gn_ab = reinterpret_cast<const float*>(1);   // (capability question only)
+    p.gn_hw = gn_hw;
+    const AfGemmPlan pl = af_plan_conv_gemm(p, 1, (int)esize(dt));
+    p.splitk = pl.splitk;
+    return af_conv_rowpanel_kind(p, 1) != 0;
+  }
+  // GroupNorm reduced to its per-sample affine map [B][2][C] for such a consumer (statistics from the producer when it left them)
+  int groupnorm_fold(const Norm& N, const Act& x, float* ab) {
+    const int HW = x.H * x.W;
+    void* ws = A.alloc(af_gn_workspace_bytes(x.B, HW));
+    if (!ws || !ab) { af_set_error_msg("arena exhausted (groupnorm fold)"); return AF_ERR_STATE; }
+    if (dry) return 0;
+    if (x.C != N.C) { af_set_error_msg("groupnorm: C mismatch %d vs %d", x.C, N.C); return AF_ERR_INVALID; }
+    const float* pre = g_af_knobs.gn_producer ? x.gn_part : nullptr;
+    return DISPATCH(dt, af_launch_groupnorm_fold<bf16>(x.p, (long)HW * x.ld, x.ld, x.B, HW, x.C, N.gamma, N.beta, N.eps, ws, s, pre, x.gn_npart, ab),
+                    af_launch_groupnorm_fold<float>(x.p, (long)HW * x.ld, x.ld, x.B, HW, x.C, N.gamma, N.beta, N.eps, ws, s, pre, x.gn_npart, ab));
+  }
   // want_gn: 1 = also write the GroupNorm partial sums of `out` into the arena (consumer inside the caller's arena scope),
   // 2 = into the handle's carry buffer (consumer = the next layer); out.gn_part is set when the launch can do it
   int conv(const Linear& L, const Act& x, Act& out, int stride, int up, const Act* residual, const void* rowbias,
@@ -860,6 +886,8 @@ struct Runner {
         p.ln_stats = ln->stats_buf;
         ln_parts_pending = true;
       }
+      p.gn_ab = ln->gn_ab;
+      p.gn_hw = ln->gn_hw;
     }
     if (x.C < L.cin || x.ld < L.cin_pad) {
       af_set_error_msg("conv: input has %d channels (ld %d), layer expects %d (padded %d)", x.C, x.ld, L.cin, L.cin_pad);
@@ -1007,10 +1035,6 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out, bool twin
     return R.copy_channels(src, dst, 0);
   };
   Act g = R.alloc_act(B, H, W, x.C);
-  {
-    Act gh = half(g);
-    AF_TRY(R.groupnorm(w.gn, x, gh, 0));
-  }
   Act t = R.alloc_act(B, H, W, C);
   // LayerNorm folding (bf16): when every GEMM around the three LayerNorms of a block runs on the ping-pong kernel in
   // one K slice, the producer of each normalised tensor also writes per-row partial sums and the consumer GEMM applies
@@ -1056,10 +1080,25 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out, bool twin
   // (rows: the statistics of a half-batch producer are laid out for ITS row count)
   auto finalize = [&](const float* st, const Norm& ln, long rows) { return R.ln_finalize(st, ln_parts, rows, C, ln.eps, st_row); };
   {
-    const Runner::LnArgs pa = producer(st_t);
-    const Act gh = half(g);
+    // GroupNorm (eps 1e-6, attention.py:71-72,325) + proj_in.  Where proj_in is a row-panel launch (64x64 / 32x32 levels, bf16)
+    // the normalisation happens in its prologue, on the activation rows it keeps in registers: no pass that reads x and writes
+    // the normalised tensor (31 / 22 us per transformer at Bf = 16), same bf16 values
+    Runner::LnArgs pa = producer(ln_parts ? st_t : nullptr);
     Act th = half(t);
-    AF_TRY(R.conv(w.proj_in, gh, th, 1, 0, nullptr, nullptr, 0, -1, -1, ln_parts ? &pa : nullptr));
+    Act xin = x;
+    xin.B = Bh;
+    const bool gn_consumer = g_af_knobs.gn_consumer && x.C == w.proj_in.cin_pad && R.rowpanel_capable(w.proj_in, xin, th, &pa, N);
+    if (gn_consumer) {
+      float* ab = reinterpret_cast<float*>(R.A.alloc((size_t)Bh * 2 * x.C * sizeof(float)));
+      AF_TRY(R.groupnorm_fold(w.gn, xin, ab));
+      pa.gn_ab = ab;
+      pa.gn_hw = N;
+      AF_TRY(R.conv(w.proj_in, xin, th, 1, 0, nullptr, nullptr, 0, -1, -1, &pa));
+    } else {
+      Act gh = half(g);
+      AF_TRY(R.groupnorm(w.gn, x, gh, 0));
+      AF_TRY(R.conv(w.proj_in, gh, th, 1, 0, nullptr, nullptr, 0, -1, -1, ln_parts ? &pa : nullptr));
+    }
   }
   for (size_t d = 0; d < w.blocks.size(); ++d) {
     const XfmrBlockW& blk = w.blocks[d];
@@ -2222,6 +2261,7 @@ int af_gemm_plan_counts(int64_t* counts10) {
 }
 int af_gemm_plan_counts_reset(void) {
   g_af_attn_short_launches = 0;
+  g_af_gn_consumer_launches = 0;
   for (int i = 0; i < 15; ++i) g_af_plan_counts[i] = 0;
   return AF_OK;
 }
@@ -2231,6 +2271,7 @@ int64_t af_rowpanel_launches(void) { return g_af_plan_counts[12]; }
 int64_t af_up_phase4_launches(void) { return g_af_plan_counts[13]; }
 int64_t af_gn_producer_launches(void) { return g_af_plan_counts[14]; }
 int64_t af_attn_short_launches(void) { return g_af_attn_short_launches; }
+int64_t af_gn_consumer_launches(void) { return g_af_gn_consumer_launches; }
 int af_set_fp8(af_handle* h, int on) {
   if (!h) { af_set_error_msg("af_set_fp8: null handle"); return AF_ERR_INVALID; }
   if (on && h->dtype != AF_DTYPE_BF16) { af_set_error_msg("af_set_fp8: the fp8 convolutions extend the bf16 mode (handle is f32)"); return AF_ERR_STATE; }

@@ -516,6 +516,71 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
   return 0;
 }
 
+// GroupNorm as a per-sample affine map for a CONSUMER that applies it itself (the row-panel proj_in GEMM of a
+// SpatialTransformer normalises its activation rows in registers: ConvGemmParams::gn_ab): ab[b][0][c] = gamma[c] * rstd,
+// ab[b][1][c] = beta[c] - mean * gamma[c] * rstd, from the same partial sums, combined in the same order and precision, as
+// gn_apply_kernel's own fold -- y = fma(x, a, b) rounded to bf16 is then bit for bit what the apply pass would have stored.
+__global__ __launch_bounds__(256) void gn_fold_kernel(const float* __restrict__ partial, int npart, double count, float eps,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int Cn, float* __restrict__ ab) {
+  __shared__ double s_ra[256], s_rq[256];
+  __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int g = tid & 31, sl = tid >> 5;
+  double a = 0.0, q = 0.0;
+  for (int c = sl; c < npart; c += 8) {
+    const float* src = partial + (((long)b * npart + c) * GN_GROUPS + g) * 2;
+    a += (double)src[0];
+    q += (double)src[1];
+  }
+  s_ra[tid] = a;
+  s_rq[tid] = q;
+  __syncthreads();
+  if (tid < 32) {
+    for (int s2 = 1; s2 < 8; ++s2) { a += s_ra[tid + 32 * s2]; q += s_rq[tid + 32 * s2]; }
+    const double mean = a / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[tid] = (float)mean;
+    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int cpg = Cn / GN_GROUPS;
+  for (int c = tid; c < Cn; c += 256) {
+    const int gg = c / cpg;
+    const float sc = gamma[c] * s_rstd[gg];
+    ab[((long)b * 2 + 0) * Cn + c] = sc;
+    ab[((long)b * 2 + 1) * Cn + c] = beta[c] - s_mean[gg] * sc;
+  }
+}
+
+template <typename T>
+int af_launch_groupnorm_fold(const void* x, long x_bs, int ldx, int B, int HW, int Cn, const float* gamma, const float* beta,
+                             float eps, void* workspace, hipStream_t stream, const float* pre_partial, int pre_npart,
+                             float* ab_out) {
+  constexpr int EPC = 16 / sizeof(T);
+  if (Cn % GN_GROUPS != 0 || Cn % EPC != 0 || Cn > GN_MAX_C || ldx % EPC != 0) {
+    af_set_error_msg("groupnorm fold: unsupported C=%d", Cn);
+    return -1;
+  }
+  int P;
+  const int nchunk = af_gn_chunking(HW, B, &P);
+  const float* partial = reinterpret_cast<float*>(workspace);
+  int npart = nchunk;
+  if (pre_partial) {
+    partial = pre_partial;
+    npart = pre_npart;
+  } else {
+    AfProfScope prof(AF_K_GROUPNORM, stream, 0.0, 1.0 * B * HW * (double)Cn * sizeof(T));
+    hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nchunk, B), dim3(256), 0, stream,
+                       reinterpret_cast<const T*>(x), x_bs, ldx, HW, Cn, P, reinterpret_cast<float*>(workspace), nchunk);
+  }
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(256), 0, stream, partial, npart, (double)HW * (double)(Cn / GN_GROUPS), eps,
+                     gamma, beta, Cn, ab_out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
 template <typename T>
 int af_launch_layernorm(const void* x, int ldx, long rows, int Cn, const float* gamma, const float* beta,
                         float eps, void* y, int ldy, hipStream_t stream, float fp8_mul) {
@@ -548,6 +613,10 @@ template int af_launch_groupnorm<bf16>(const void*, long, int, int, int, int, co
                                        int, void*, long, int, void*, hipStream_t, float, const float*, int);
 template int af_launch_groupnorm<float>(const void*, long, int, int, int, int, const float*, const float*, float,
                                         int, void*, long, int, void*, hipStream_t, float, const float*, int);
+template int af_launch_groupnorm_fold<bf16>(const void*, long, int, int, int, int, const float*, const float*, float, void*,
+                                            hipStream_t, const float*, int, float*);
+template int af_launch_groupnorm_fold<float>(const void*, long, int, int, int, int, const float*, const float*, float, void*,
+                                             hipStream_t, const float*, int, float*);
 template int af_launch_layernorm<bf16>(const void*, int, long, int, const float*, const float*, float, void*, int,
                                        hipStream_t, float);
 template int af_launch_layernorm<float>(const void*, int, long, int, const float*, const float*, float, void*,

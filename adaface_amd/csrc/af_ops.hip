@@ -300,6 +300,66 @@ int af_op_linear(int dtype, const float* x_dev, const float* w_dev, const float*
   return 0;
 }
 
+// GroupNorm (no SiLU) followed by a 1x1 convolution -- SpatialTransformer.norm + proj_in (attention.py:325-326) -- both ways
+// on the same bf16 operands: y_plain = the apply pass + the GEMM, y_fused = the row-panel GEMM normalising its rows in its
+// prologue (ConvGemmParams::gn_ab).  Outputs [B, N, H, W] fp32.  Fails when the shape has no row-panel launch.
+int af_op_gn_conv1x1(const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, const float* w_dev,
+                     const float* bias_dev, float* y_plain_dev, float* y_fused_dev, int B, int C, int H, int W, int N,
+                     void* stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Tmp tmp;
+  const int HW = H * W, rows_pad = rup(N, 128);
+  if (C % 64 || N % 4) { af_set_error_msg("af_op_gn_conv1x1: C %% 64 and N %% 4"); return AF_ERR_INVALID; }
+  OP_ALLOC(xn, (size_t)B * HW * C * 2, false);
+  OP_ALLOC(gn, (size_t)B * HW * C * 2, false);
+  OP_ALLOC(wn, (size_t)rows_pad * C * 2, true);
+  OP_ALLOC(y0, (size_t)B * HW * N * 2, true);
+  OP_ALLOC(y1, (size_t)B * HW * N * 2, true);
+  OP_ALLOC(ws, af_gn_workspace_bytes(B, HW), false);
+  OP_ALLOC(ab, (size_t)B * 2 * C * sizeof(float), false);
+  float* bn = nullptr;
+  if (bias_dev) {
+    bn = reinterpret_cast<float*>(tmp.get((size_t)rows_pad * 4, true));
+    if (!bn) return AF_ERR_HIP;
+    if (hipMemcpyAsync(bn, bias_dev, (size_t)N * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return AF_ERR_HIP;
+  }
+  OP_TRY(af_launch_nchw_to_nhwc<bf16>(x_dev, xn, B, C, HW, C, 1.f, s));
+  OP_TRY(af_launch_repack_weight<bf16>(w_dev, wn, N, C, C, 1, C, 0, 0, s));
+  ConvGemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.src_batch_stride = (long)HW * C; p.ldc = C; p.Cin = C;
+  p.Hs = H; p.Ws = W; p.Hi = H; p.Wi = W; p.Ho = H; p.Wo = W;
+  p.ks = 1; p.stride = 1; p.pad = 0;
+  p.W = wn; p.ldw = C; p.Wrows = rows_pad;
+  p.M = B * HW; p.N = N; p.K = C; p.k_logical = C;
+  p.bias = bn; p.ldo = N; p.alpha = 1.f;
+  // plain: GroupNorm apply pass, then the GEMM as the planner places it
+  OP_TRY(af_launch_groupnorm<bf16>(xn, (long)HW * C, C, B, HW, C, gamma_dev, beta_dev, eps, 0, gn, (long)HW * C, C, ws, s));
+  {
+    ConvGemmParams q = p;
+    q.src = gn; q.out = y0;
+    const AfGemmPlan pl = af_plan_conv_gemm(q, 1, 2);
+    void* wsk = nullptr;
+    if (pl.splitk > 1) { wsk = tmp.get(pl.ws_bytes, false); if (!wsk) return AF_ERR_HIP; }
+    OP_TRY(af_launch_conv_gemm<bf16>(q, 1, s, &pl, wsk));
+  }
+  // fused: statistics + fold, the GEMM reads the un-normalised rows
+  OP_TRY(af_launch_groupnorm_fold<bf16>(xn, (long)HW * C, C, B, HW, C, gamma_dev, beta_dev, eps, ws, s, nullptr, 0, (float*)ab));
+  {
+    ConvGemmParams q = p;
+    q.src = xn; q.out = y1;
+    q.gn_ab = (const float*)ab; q.gn_hw = HW;
+    AfGemmPlan pl = af_plan_conv_gemm(q, 1, 2);
+    q.splitk = pl.splitk;
+    if (!af_conv_rowpanel_kind(q, 1)) { af_set_error_msg("af_op_gn_conv1x1: M=%d K=%d N=%d has no row-panel launch", q.M, q.K, q.N); return AF_ERR_INVALID; }
+    q.splitk = 0;
+    OP_TRY(af_launch_conv_gemm<bf16>(q, 1, s, &pl, nullptr));
+  }
+  OP_TRY(af_launch_nhwc_to_nchw<bf16>(y0, y_plain_dev, B, N, HW, N, s));
+  OP_TRY(af_launch_nhwc_to_nchw<bf16>(y1, y_fused_dev, B, N, HW, N, s));
+  return 0;
+}
+
 int af_op_groupnorm(int dtype, const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, int silu,
                     float* y_dev, int B, int C, int H, int W, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -130,6 +130,21 @@ def conv_gn(x, w, b, gamma, beta, eps=1e-5, silu=True, residual=None):
     return h, y
 
 
+def gn_conv1x1(x, gamma, beta, w, bias=None, eps=1e-6):
+    """GroupNorm(32) + 1x1 convolution (SpatialTransformer.norm + proj_in) in bf16, both ways (af_op_gn_conv1x1): returns
+    (plain, fused) = (apply pass + GEMM, row-panel GEMM with the GroupNorm in its prologue), each [B, N, H, W]."""
+    lib = _lib.load()
+    x = _dev_f32(x)
+    B, Cn, H, W = x.shape
+    N = w.shape[0]
+    y0 = torch.empty(B, N, H, W, device=x.device, dtype=torch.float32)
+    y1 = torch.empty_like(y0)
+    check(lib.af_op_gn_conv1x1(ptr(x), ptr(_dev_f32(gamma)), ptr(_dev_f32(beta)), eps, ptr(_dev_f32(w.reshape(N, Cn))),
+                               ptr(_dev_f32(bias)) if bias is not None else None, ptr(y0), ptr(y1), B, Cn, H, W, N, stream_ptr()),
+          "af_op_gn_conv1x1")
+    return y0, y1
+
+
 def layer_norm(x, weight, bias, eps=1e-5, dtype="bf16"):
     lib = _lib.load()
     x = _dev_f32(x)

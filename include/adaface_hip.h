@@ -242,6 +242,8 @@ int64_t af_gn_producer_launches(void); /* convolutions that also wrote the Group
 /* launches of the register-resident short-key cross-attention kernel (bf16, <= 96 keys, dh 40 / 80) since the last
  * af_gemm_plan_counts_reset */
 int64_t af_attn_short_launches(void);
+/* row-panel GEMM launches that applied the GroupNorm of their input in their prologue (SpatialTransformer.norm + proj_in) */
+int64_t af_gn_consumer_launches(void);
 int64_t af_up_phase4_launches(void); /* upsampled 3x3 convolutions run as four 2x2 phase convolutions on the stored map */
 int64_t af_rowpanel_launches(void); /* launches of the row-panel kernels (K = 320 / 640 / 1280 GEMMs with the activation rows resident in registers) */
 int af_op_conv2d_fp8(const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev, float* y_dev,
@@ -251,6 +253,12 @@ int af_op_groupnorm_fp8(const float* x_dev, const float* gamma_dev, const float*
                         unsigned char* y8_dev, int B, int C, int H, int W, int act_shift, void* stream);
 int af_op_layernorm_fp8(const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, unsigned char* y8_dev,
                         int64_t rows, int C, int act_shift, void* stream);
+/* GroupNorm(32) (no SiLU) + 1x1 convolution (SpatialTransformer.norm + proj_in, attention.py:325-326) on the same bf16
+ * operands both ways: y_plain = apply pass + GEMM, y_fused = row-panel GEMM that normalises its rows in its prologue.
+ * x [B,C,H,W], w [N,C], outputs [B,N,H,W] fp32; fails when the shape has no row-panel launch. */
+int af_op_gn_conv1x1(const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, const float* w_dev,
+                     const float* bias_dev, float* y_plain_dev, float* y_fused_dev, int B, int C, int H, int W, int N,
+                     void* stream);
 /* F.layer_norm over the last dim of [rows, C]. */
 int af_op_layernorm(int dtype, const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps,
                     float* y_dev, int64_t rows, int C, void* stream);

@@ -321,6 +321,38 @@ def test_sd15_unet_layernorm_folding_ab(gpu, report, knobs):
     _assert_bf16_ab(report, "sd15_unet Bf=16 LayerNorm-folded (A) vs stand-alone LayerNorm (B)", eps_fused, eps_plain, ref)
 
 
+def test_sd15_unet_new_fused_paths_ab(gpu, report, knobs):
+    """Round-3 fusions at the benchmark batch, each against the forward without it (knob off) and both against the f32-mode
+    forward (derived bf16 bars, _assert_bf16_ab): the register-resident short-key cross-attention kernel, and the
+    SpatialTransformer GroupNorm applied in the prologue of the row-panel proj_in."""
+    from adaface_amd import _lib
+    from adaface_amd.engine import Engine
+    from adaface_amd.synth import synth_weights_into
+    cfg = O.SD15_UNET
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(16, 4, 64, 64, generator=g).to(gpu)
+    t = torch.randint(0, 1000, (16,), generator=g).to(gpu)
+    ctx = torch.randn(16 * 16, 77, cfg.context_dim, generator=g).to(gpu)
+    eng = Engine(dtype="bf16", unet=_unet_kwargs(cfg))
+    synth_weights_into(eng, O.unet_param_shapes(cfg), seed=62, device=gpu)
+    eng.set_context(ctx, 16, layerwise=True)
+    _lib.plan_counts(reset=True)
+    full = eng.unet_forward(x, t)
+    pc = _lib.plan_counts(reset=True)
+    assert pc["attn_short"] == 10 and pc["gn_consumer"] == 10, pc
+    outs = {}
+    for knob in ("attn_short", "gn_consumer"):
+        knobs(knob, 0)
+        outs[knob] = eng.unet_forward(x, t)
+        pc0 = _lib.plan_counts(reset=True)
+        assert pc0[knob] == 0, pc0
+        knobs(knob, 1)
+    eng.close()
+    ref = _f32_mode_forward(gpu, cfg, 62, x, t, ctx, 16)
+    for knob, out in outs.items():
+        _assert_bf16_ab(report, f"sd15_unet Bf=16 with (A) / without (B) {knob}", full, out, ref)
+
+
 def test_sd15_unet_batch_consistency(gpu, report):
     """f32 mode: Bf = 16 vs Bf = 2 pairs agree to 1e-5 (summation order only).  bf16 mode: two tilings round their
     activations differently; the Bf = 16 forward and every Bf = 2 pair are held to the per-forward bar against the
@@ -354,6 +386,8 @@ def test_sd15_unet_batch_consistency(gpu, report):
             assert pc["gn_producer"] >= 15, pc
             # the ten cross-attention layers of the 64x64 / 32x32 levels on the register-resident short-key kernel
             assert pc["attn_short"] == 10, pc
+            # ... and their GroupNorm applied in the prologue of the row-panel proj_in
+            assert pc["gn_consumer"] == 10, pc
             e16 = (eps16 - eps_f32).abs().max().item() / eps_f32.abs().max().item()
             report("sd15_unet Bf=16 bf16 forward vs f32-mode forward of the same batch", e16, eps_f32.abs().max().item(), BF16_FWD_BAR)
             assert e16 <= BF16_FWD_BAR, e16

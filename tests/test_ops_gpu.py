@@ -254,6 +254,31 @@ def test_conv_gn_producer_refuses_sliced_k(gpu):
         ops.conv_gn(x, w, None, ones, ones * 0)
 
 
+@pytest.mark.parametrize("B,C,H,W,N", [(8, 320, 64, 64, 320), (16, 640, 32, 32, 640), (9, 320, 64, 64, 960)])
+def test_groupnorm_in_rowpanel_prologue(gpu, report, B, C, H, W, N):
+    """SpatialTransformer.norm + proj_in with the GroupNorm applied in the row-panel GEMM's prologue (ConvGemmParams::gn_ab):
+    the rows it normalises in registers are bit for bit what gn_apply_kernel would have stored, so at K = 320 -- where the
+    un-fused launch runs on the same kernel -- the two outputs are IDENTICAL; at K = 640 the un-fused GEMM is the tiled
+    kernel (other summation order): bf16 bar.  Both against torch."""
+    from adaface_amd import _lib, ops
+    g = torch.Generator().manual_seed(B + C + N)
+    x = _q(torch.randn(B, C, H, W, generator=g) * 1.3 + 0.5 * torch.randn(B, C, 1, 1, generator=g), "bf16")
+    gamma = torch.randn(C, generator=g) * 0.2 + 1.0
+    beta = torch.randn(C, generator=g) * 0.2
+    w = torch.randn(N, C, generator=g) / math.sqrt(C)
+    b = torch.randn(N, generator=g) * 0.1
+    _lib.plan_counts(reset=True)
+    plain, fused = ops.gn_conv1x1(x.to(gpu), gamma.to(gpu), beta.to(gpu), w.to(gpu), b.to(gpu), eps=1e-6)
+    assert _lib.plan_counts(reset=True)["gn_consumer"] == 1
+    ref = torch.nn.functional.conv2d(torch.nn.functional.group_norm(x, 32, gamma, beta, 1e-6), _q(w, "bf16").view(N, C, 1, 1), b)
+    _cmp(report, f"groupnorm in row-panel prologue B{B} C{C} {H}x{W} N{N} (fused)", fused, ref, "bf16")
+    _cmp(report, f"groupnorm + GEMM (plain) B{B} C{C} {H}x{W} N{N}", plain, ref, "bf16")
+    if C == 320:
+        assert torch.equal(plain, fused)
+    else:
+        _cmp(report, f"groupnorm in row-panel prologue vs plain C{C}", fused, plain, "bf16")
+
+
 @pytest.mark.parametrize("M,K,N,bias", [(32768, 320, 1280, True), (32868, 320, 640, False), (65536, 320, 1280, True),
                                         (16384, 640, 2560, True), (16434, 640, 192, False), (32768, 640, 2560, False)])
 def test_geglu_rowpanel(gpu, report, knobs, M, K, N, bias):
