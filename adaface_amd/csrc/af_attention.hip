@@ -750,19 +750,17 @@ __global__ __launch_bounds__(256) void xattn_short_kernel(const AttnParams p, co
   const int nblk = (p.Nq + 31) / 32;
   const int blk0 = blockIdx.x * bpw, blk1 = blk0 + bpw < nblk ? blk0 + bpw : nblk;
   if (blk0 >= nblk) return;
-  uint4 qn[C::KS];
-  load_q(blk0, qn);
-  for (int blk = blk0; blk < blk1; ++blk) {
+  // one block of 32 queries (fragments qraw, as loaded): S^T, softmax, O^T, store
+  auto body = [&](const uint4 (&qraw)[C::KS], int blk) {
     uint4 qf[C::KS];
 #pragma unroll
     for (int s = 0; s < C::KS; ++s) {   // pre-scale by scale * log2(e): softmax is then exp2(s - m)
       Vec16<T> v;
-      v.u = qn[s];
+      v.u = qraw[s];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v.e[e] = from_f32<T>(to_f32<T>(v.e[e]) * sl2);
       qf[s] = v.u;
     }
-    if (blk + 1 < blk1) load_q(blk + 1, qn);
     // ---- S^T = K Q^T ----
     f32x16 sc[NKB];
 #pragma unroll
@@ -819,6 +817,24 @@ __global__ __launch_bounds__(256) void xattn_short_kernel(const AttnParams p, co
           if (q < p.Nq) ov.store(O + (long)q * p.ldo + dd);
         }
       }
+  };
+  // Q fragments of THREE blocks in flight (a three-register ring, statically indexed): with one block ahead the wave had
+  // ~3 KB of loads outstanding and the launch ran at the memory latency (1.3 TB/s of Q + O traffic), not at its bandwidth
+  uint4 q0[C::KS], q1[C::KS], q2[C::KS];
+  load_q(blk0, q0);
+  load_q(blk0 + 1, q1);           // (blocks past the end load nothing: q >= Nq)
+  load_q(blk0 + 2, q2);
+  for (int blk = blk0; blk < blk1; blk += 3) {
+    body(q0, blk);
+    if (blk + 3 < blk1) load_q(blk + 3, q0);
+    if (blk + 1 < blk1) {
+      body(q1, blk + 1);
+      if (blk + 4 < blk1) load_q(blk + 4, q1);
+    }
+    if (blk + 2 < blk1) {
+      body(q2, blk + 2);
+      if (blk + 5 < blk1) load_q(blk + 5, q2);
+    }
   }
 }
 }  // namespace xs

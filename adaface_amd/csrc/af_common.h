@@ -98,6 +98,7 @@ struct AfKnobs {
   int pp_sched;             // AF_PP_SCHED             eight-wave kernel: 0 = round-1 compute phase (two K halves, a full LDS drain
                             //                         after each), 1 = block-ordered compute phase, 2 = merged (no staging phase)
   int attn_short;           // AF_ATTN_SHORT           0 = cross-attention (<= 96 keys) stays on the flash kernels
+  int rowpanel_deep;        // AF_ROWPANEL_DEEP        0 = row-panel kernels keep the round-2 weight ring (3 slots, prefetch distance 2)
   int gn_consumer;          // AF_GN_CONSUMER          0 = the SpatialTransformer's GroupNorm always runs its own apply pass (never
                             //                         in the prologue of a row-panel proj_in)
 };

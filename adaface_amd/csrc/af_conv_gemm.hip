@@ -1615,27 +1615,33 @@ __global__ __launch_bounds__(512) void conv3x3_halo8_kernel(const ConvGemmParams
 // the tiled kernel).
 // KC_ = 10, MJ_ = 1: the K = 640 form for the 32x32-level transformers (16 rows per wave keep the fragment registers at 80;
 // 128-row panels, and the column tiles of a panel split over gridDim.y workgroups so that 16384 rows still fill 256 CUs).
-template <bool GEGLU, int KC_ = 5, int MJ_ = 2> struct RowPanelCfgT {
-  static constexpr int KC = KC_, MJ = MJ_, K = KC * 64;
+// D_ = prefetch distance of the weight ring in K steps (the ring has D_ + 1 slots).  Round 2 shipped D = 2: a step then
+// waits for an LDS-DMA issued two steps earlier, and with 16-32 MFMAs per wave and step (0.12-0.25 us of matrix time) the
+// ~1.1 us a DMA takes from issue to landing set the step time (0.55 us at K = 640).  Where the LDS allows it the ring is
+// now deeper: GEGLU forms 6 slots (D = 5), plain forms with 16 rows per wave 5 slots (D = 4); the plain K = 320 form keeps
+// D = 2 (its 32-row output transposition tiles leave room for three 20 KB slots only).  D <= KC: at most one tile's output
+// stores are then younger than the pieces a wait covers.
+template <bool GEGLU, int KC_ = 5, int MJ_ = 2, int D_ = 2> struct RowPanelCfgT {
+  static constexpr int KC = KC_, MJ = MJ_, K = KC * 64, D = D_, NS = D_ + 1;
   static constexpr int WROWS = 16 * MJ, BM = 8 * WROWS;             // rows per wave / per workgroup
   static constexpr int BN = GEGLU ? 128 : 160;
   static constexpr int WBYTES = BN * 128, WPIECES = BN / 8;
   static constexpr int NIW = BN / 16;              // weight blocks per column tile
   static constexpr int OCOLS = GEGLU ? BN / 2 : BN;                 // output columns per tile
   static constexpr int OPITCH = OCOLS * 2 + 16, OBYTES = WROWS * OPITCH;   // per-wave output transposition tile (bf16)
-  static constexpr int LDS_BYTES = 3 * WBYTES + 8 * OBYTES;
+  static constexpr int LDS_BYTES = NS * WBYTES + 8 * OBYTES;
   static constexpr int CPR = OCOLS / 8;            // 16-byte chunks per output row segment
   static constexpr int NST = WROWS * CPR / 64;     // 16-byte buffer stores per lane and column tile
-  static_assert(LDS_BYTES <= 160 * 1024 && (WROWS * CPR) % 64 == 0 && (MJ * KC == 10 || (MJ == 1 && KC == 20)),
-                "row-panel LDS / store mapping / 80 (K = 1280, 16 rows per wave: 160) fragment registers");
+  static_assert(LDS_BYTES <= 160 * 1024 && (WROWS * CPR) % 64 == 0 && (MJ * KC == 10 || (MJ == 1 && KC == 20)) && D >= 2 && D <= KC,
+                "row-panel LDS / store mapping / 80 (K = 1280, 16 rows per wave: 160) fragment registers / ring depth");
 };
 typedef RowPanelCfgT<true> RowPanelCfg;
 
-template <bool GEGLU, int LNMODE, bool RES, int KC_ = 5, int MJ_ = 2>
+template <bool GEGLU, int LNMODE, bool RES, int KC_ = 5, int MJ_ = 2, int D_ = 2>
 __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
-  using C = RowPanelCfgT<GEGLU, KC_, MJ_>;
+  using C = RowPanelCfgT<GEGLU, KC_, MJ_, D_>;
   typedef bf16 T;
-  constexpr int KC = C::KC, NIW = C::NIW, MJ = C::MJ, NST = C::NST, CPR = C::CPR;
+  constexpr int KC = C::KC, NIW = C::NIW, MJ = C::MJ, NST = C::NST, CPR = C::CPR, D = C::D, NS = C::NS;
   static_assert(!(GEGLU && (RES || LNMODE == 2)), "GEGLU: plain or LayerNorm-consumer epilogue, no residual");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1672,26 +1678,6 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
 #pragma unroll
       for (int u = 0; u < 2; ++u)
         xr[j][kc][u] = __builtin_bit_cast(pp_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xo, (kc * 64 + u * 32) * 2, 0));
-    if (p.gn_ab) {
-      // GroupNorm of the consumer's input (see ConvGemmParams::gn_ab): the panel lies inside one sample
-      const float* ga = p.gn_ab + (long)(m0 / p.gn_hw) * 2 * C::K + 8 * (lane >> 4);
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const float* gp = ga + kc * 64 + u * 32;
-          float sc[8], sh[8];
-          *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(gp);
-          *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(gp + 4);
-          *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(gp + C::K);
-          *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(gp + C::K + 4);
-          Vec16<T> v;
-          v.u = __builtin_bit_cast(uint4, xr[j][kc][u]);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v.e[e] = from_f32<T>(fmaf(to_f32<T>(v.e[e]), sc[e], sh[e]));
-          xr[j][kc][u] = __builtin_bit_cast(pp_u32x4, v.u);
-        }
-    }
     if constexpr (LNMODE == 1) {
       float2 st = float2{0.f, 0.f};
       if (ok && p.ln_parts_n > 0) {
@@ -1712,6 +1698,31 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
       ln_mu[j] = st.x;
       ln_rs[j] = st.y;
     }
+  }
+
+  if (p.gn_ab) {
+    // GroupNorm of the consumer's input (see ConvGemmParams::gn_ab), after every row load of the wave has been issued: the
+    // panel lies inside one sample, so all rows share the (scale, shift) vectors of the channels this lane holds
+    const float* ga = p.gn_ab + (long)(m0 / p.gn_hw) * 2 * C::K + 8 * (lane >> 4);
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float* gp = ga + kc * 64 + u * 32;
+        float sc[8], sh[8];
+        *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(gp);
+        *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(gp + 4);
+        *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(gp + C::K);
+        *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(gp + C::K + 4);
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+          Vec16<T> v;
+          v.u = __builtin_bit_cast(uint4, xr[j][kc][u]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v.e[e] = from_f32<T>(fmaf(to_f32<T>(v.e[e]), sc[e], sh[e]));
+          xr[j][kc][u] = __builtin_bit_cast(pp_u32x4, v.u);
+        }
+      }
   }
 
   // ---- weight staging: tile (nt, kc) = rows nt * BN .. of W, bytes kc * 128 .. + 127 of each; piece = 8 rows ----
@@ -1745,7 +1756,7 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
 #else
   constexpr int lab = 0;
 #endif
-  char* otile = smem + 3 * C::WBYTES + wid * C::OBYTES;
+  char* otile = smem + NS * C::WBYTES + wid * C::OBYTES;
   f32x4 acc[NIW][MJ];
   pp_u32x4 wf[NIW][2];
   auto zero_acc = [&]() {
@@ -1759,7 +1770,7 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
     constexpr int n = decltype(nc)::value;
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(blk[0]), "+v"(blk[1]) : "n"(n) : "memory");
   };
-  // one K step of one column tile: weight blocks read two ahead of their MFMAs, counted waits; DMA for step t + 2
+  // one K step of one column tile: weight blocks read two ahead of their MFMAs, counted waits; DMA for step t + D
   auto step = [&](auto kcc, int slot, int t, int stage_slot) {
     constexpr int kc = decltype(kcc)::value;
     const unsigned b0 = lds0 + (unsigned)(slot * C::WBYTES) + w_base + fch0;
@@ -1786,32 +1797,34 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
         asm volatile("" : "+v"(acc[i][j]));
       }
       if constexpr (i + 3 < NIW) rd(std::integral_constant<int, i + 3>{});
-      if constexpr (i == 1) { if (!(lab & 1)) stage(t + 2, stage_slot); }
+      if constexpr (i == 1) { if (!(lab & 1)) stage(t + D, stage_slot); }
       __builtin_amdgcn_sched_barrier(0);
     });
     pp_wait_lgkm0();
   };
 
-  // ---- main loop: steps t = (column tile, K chunk); tiles 0 / 1 of the ring in flight ----
-  stage(0, 0);
-  stage(1, 1);
-  int s0 = 0, s1 = 1, s2 = 2;
+  // ---- main loop: steps t = (column tile, K chunk); steps 0 .. D-1 of the ring in flight; step t sits in slot t % NS and
+  // the DMA for step t + D goes to slot (t + D) % NS = the slot step t - 1 has just left (every wave is past this step's barrier)
+#pragma unroll
+  for (int i = 0; i < D; ++i) stage(i, i);
+  int cur = 0;
   int after_epi = 0;                               // heads that still see the previous tile's stores in the counter
   for (int ntl = 0; ntl < ntn; ++ntl) {
     const int nt = nt_begin + ntl;
     pp_static_for<0, KC>([&](auto kcc) {
       constexpr int kc = decltype(kcc)::value;
-      // own pieces of this step landed: everything but the pieces of the next step (and, for two heads after an epilogue,
+      // own pieces of this step landed: everything but the pieces of the next D - 1 steps (and, for D heads after an epilogue,
       // its NST stores, which are YOUNGER than the pieces waited for).  (BN = 160: waves 0-3 stage three pieces a step.)
       if (after_epi > 0) {
-        if (nwq == 3) pp_wait_vm<3 + NST>(); else pp_wait_vm<2 + NST>();
+        if (nwq == 3) pp_wait_vm<3 * (D - 1) + NST>(); else pp_wait_vm<2 * (D - 1) + NST>();
         --after_epi;
       } else {
-        if (nwq == 3) pp_wait_vm<3>(); else pp_wait_vm<2>();
+        if (nwq == 3) pp_wait_vm<3 * (D - 1)>(); else pp_wait_vm<2 * (D - 1)>();
       }
       __builtin_amdgcn_s_barrier();
-      step(kcc, s0, ntl * KC + kc, s2);
-      const int tmp = s0; s0 = s1; s1 = s2; s2 = tmp;
+      const int prev = cur == 0 ? NS - 1 : cur - 1;
+      step(kcc, cur, ntl * KC + kc, prev);
+      cur = cur + 1 == NS ? 0 : cur + 1;
     });
     // ---- epilogue of the column tile (every bias / column-sum / residual vector is fetched first: one memory round trip) ----
     if (lab & 8) continue;
@@ -1928,23 +1941,32 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
       __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, orow[i], ncol * 2, 0);
     }
     zero_acc();
-    after_epi = 2;
+    after_epi = D;
   }
   pp_wait_vm<0>();
 }
 
-template <bool GEGLU, int LNMODE, bool RES, int KC = 5, int MJ = 2>
-static int launch_rowpanel_one(const ConvGemmParams& p, hipStream_t stream) {
-  using C = RowPanelCfgT<GEGLU, KC, MJ>;
+template <bool GEGLU, int LNMODE, bool RES, int KC, int MJ, int D>
+static int launch_rowpanel_depth(const ConvGemmParams& p, hipStream_t stream) {
+  using C = RowPanelCfgT<GEGLU, KC, MJ, D>;
   static unsigned long long attr_done = 0;
-  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&rowpanel_kernel<GEGLU, LNMODE, RES, KC, MJ>), C::LDS_BYTES)) return rc;
+  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&rowpanel_kernel<GEGLU, LNMODE, RES, KC, MJ, D>), C::LDS_BYTES)) return rc;
   const int panels = (p.M + C::BM - 1) / C::BM, ntn = p.N / C::BN;
   int ny = 1;                                       // column tiles of a panel over ny workgroups until ~256 exist
   while (panels * ny < 192 && ny * 2 <= ntn && ntn % (ny * 2) == 0) ny *= 2;
   dim3 grid(panels, ny, 1);
-  hipLaunchKernelGGL((rowpanel_kernel<GEGLU, LNMODE, RES, KC, MJ>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((rowpanel_kernel<GEGLU, LNMODE, RES, KC, MJ, D>), grid, dim3(512), C::LDS_BYTES, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
+}
+// ring depth: the deepest the form's LDS allows (see RowPanelCfgT), or the round-2 depth of 2 with knob rowpanel_deep = 0
+template <bool GEGLU, int LNMODE, bool RES, int KC = 5, int MJ = 2>
+static int launch_rowpanel_one(const ConvGemmParams& p, hipStream_t stream) {
+  constexpr int DEEP = GEGLU ? 5 : (MJ == 1 ? 4 : 2);
+  if constexpr (DEEP != 2) {
+    if (g_af_knobs.rowpanel_deep) return launch_rowpanel_depth<GEGLU, LNMODE, RES, KC, MJ, DEEP>(p, stream);
+  }
+  return launch_rowpanel_depth<GEGLU, LNMODE, RES, KC, MJ, 2>(p, stream);
 }
 // (k640: the 32x32-level form, K = 640, 16 rows per wave)
 static int launch_geglu_rowpanel(const ConvGemmParams& p, hipStream_t stream, bool k640 = false) {
@@ -2775,8 +2797,8 @@ int af_conv_rowpanel_kind(const ConvGemmParams& p, int batch) {
   if (p.K == 640 && lvl >= 3 && p.M >= 16384 && !p.residual) {
     if (p.gn_ab) {
       // proj_in of a 32x32-level transformer with its GroupNorm applied in the prologue: N = 640 is short for this kernel (the
-      // tiled one measures ahead on the bare GEMM), but the GroupNorm pass it saves is as long as the GEMM itself
-      return (!geglu && p.gn_hw > 0 && p.gn_hw % 128 == 0 && p.N % 160 == 0 && p.alpha == 1.0f && !p.ln_stats) ? 5 : 0;
+      // tiled one measures ahead on the bare GEMM); knob gn_consumer >= 2 only
+      return (g_af_knobs.gn_consumer >= 2 && !geglu && p.gn_hw > 0 && p.gn_hw % 128 == 0 && p.N % 160 == 0 && p.alpha == 1.0f && !p.ln_stats) ? 5 : 0;
     }
     if (p.ln_stats_out) return 0;
     if (geglu) return p.N % 128 == 0 ? 4 : 0;

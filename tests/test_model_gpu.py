@@ -339,7 +339,7 @@ def test_sd15_unet_new_fused_paths_ab(gpu, report, knobs):
     _lib.plan_counts(reset=True)
     full = eng.unet_forward(x, t)
     pc = _lib.plan_counts(reset=True)
-    assert pc["attn_short"] == 10 and pc["gn_consumer"] == 10, pc
+    assert pc["attn_short"] == 10 and pc["gn_consumer"] == 5, pc
     outs = {}
     for knob in ("attn_short", "gn_consumer"):
         knobs(knob, 0)
@@ -386,8 +386,8 @@ def test_sd15_unet_batch_consistency(gpu, report):
             assert pc["gn_producer"] >= 15, pc
             # the ten cross-attention layers of the 64x64 / 32x32 levels on the register-resident short-key kernel
             assert pc["attn_short"] == 10, pc
-            # ... and their GroupNorm applied in the prologue of the row-panel proj_in
-            assert pc["gn_consumer"] == 10, pc
+            # ... and the GroupNorm of the 64x64-level ones applied in the prologue of the row-panel proj_in
+            assert pc["gn_consumer"] == 5, pc
             e16 = (eps16 - eps_f32).abs().max().item() / eps_f32.abs().max().item()
             report("sd15_unet Bf=16 bf16 forward vs f32-mode forward of the same batch", e16, eps_f32.abs().max().item(), BF16_FWD_BAR)
             assert e16 <= BF16_FWD_BAR, e16
