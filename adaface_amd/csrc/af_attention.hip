@@ -727,8 +727,14 @@ __global__ __launch_bounds__(256) void xattn_short_kernel(const AttnParams p, co
 #pragma unroll
     for (int s = 0; s < C::KS; ++s) {
       const int key = 32 * kb + l31, d0 = 16 * s + 8 * h;
-      kf[kb][s] = make_uint4(0, 0, 0, 0);
-      if (key < p.Nk && d0 < DH) kf[kb][s] = *reinterpret_cast<const uint4*>(K + (long)key * p.ldk + d0);
+      Vec16<T> v;
+      v.u = make_uint4(0, 0, 0, 0);
+      if (key < p.Nk && d0 < DH) v.u = *reinterpret_cast<const uint4*>(K + (long)key * p.ldk + d0);
+      // scale * log2(e) rides on the resident K fragments (rounded to bf16 once per wave, as the flash kernels round their
+      // pre-scaled Q): the per-block Q fragments go into the MFMA as loaded, and softmax is exp2(s - m)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v.e[e] = from_f32<T>(to_f32<T>(v.e[e]) * sl2);
+      kf[kb][s] = v.u;
     }
   uint4 vf[C::DB][C::VSTEPS];
   {
@@ -751,16 +757,7 @@ __global__ __launch_bounds__(256) void xattn_short_kernel(const AttnParams p, co
   const int blk0 = blockIdx.x * bpw, blk1 = blk0 + bpw < nblk ? blk0 + bpw : nblk;
   if (blk0 >= nblk) return;
   // one block of 32 queries (fragments qraw, as loaded): S^T, softmax, O^T, store
-  auto body = [&](const uint4 (&qraw)[C::KS], int blk) {
-    uint4 qf[C::KS];
-#pragma unroll
-    for (int s = 0; s < C::KS; ++s) {   // pre-scale by scale * log2(e): softmax is then exp2(s - m)
-      Vec16<T> v;
-      v.u = qraw[s];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v.e[e] = from_f32<T>(to_f32<T>(v.e[e]) * sl2);
-      qf[s] = v.u;
-    }
+  auto body = [&](const uint4 (&qf)[C::KS], int blk) {
     // ---- S^T = K Q^T ----
     f32x16 sc[NKB];
 #pragma unroll
@@ -773,12 +770,16 @@ __global__ __launch_bounds__(256) void xattn_short_kernel(const AttnParams p, co
     // ---- exact softmax over the keys < Nk this lane's query column holds (rows split over the two lane halves) ----
     float mx = -INFINITY;
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (32 * kb + 32 > p.Nk) {       // (wave-uniform) only a partial or empty key block has rows to mask
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (32 * kb + acc_row(r, h) >= p.Nk) sc[kb][r] = -INFINITY;
-        mx = fmaxf(mx, sc[kb][r]);
+        for (int r = 0; r < 16; ++r)
+          if (32 * kb + acc_row(r, h) >= p.Nk) sc[kb][r] = -INFINITY;
       }
+      // (plain fmaxf: an inline-asm v_max3 reading MFMA results would need its own wait states, see the flash kernels)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
+    }
     mx = xhalf_max(mx);
     uint4 pb[NKB][2];
 #pragma unroll
@@ -899,11 +900,13 @@ long g_af_attn_short_launches = 0;
 
 template <int DH> static int launch_xattn_short(const AttnParams& p, int B, hipStream_t stream) {
   const int nblk = (p.Nq + 31) / 32;
-  // blocks of 32 queries per wave: enough waves to cover the chip twice (1024 SIMDs), at most 8 blocks each
+  // blocks of 32 queries per wave: the launch should fit the chip in ONE round of workgroups (every wave pays the load of its
+  // resident K / V^T fragments): 1024 SIMDs x the waves per SIMD the kernel's registers allow (dh 40: two, dh 80: one)
   const long wave_blocks = (long)B * p.H * nblk;
-  int bpw = (int)(wave_blocks / 2048);
+  const long slots = 1024L * (DH == 40 ? 2 : 1);
+  int bpw = (int)((wave_blocks + slots - 1) / slots);
   if (bpw < 1) bpw = 1;
-  if (bpw > 8) bpw = 8;
+  if (bpw > 16) bpw = 16;
   dim3 grid((nblk + bpw - 1) / bpw, (p.H + 3) / 4, B);
   hipLaunchKernelGGL((xs::xattn_short_kernel<DH>), grid, dim3(256), 0, stream, p, reinterpret_cast<const bf16*>(p.vt_pack), bpw);
   HIP_CHECK_RET(hipGetLastError());
