@@ -298,6 +298,9 @@ def main():
                     "event_pair_overhead_us_subtracted": ev_us,
                     "algorithmic_bytes_per_launch": byts[d] / launches[d],
                     "traffic": traffic, "traffic_source": tsrc,
+                    # the same against what THIS device sustains on a register-only MFMA loop (device_clock_probe): under a
+                    # dense MFMA stream the chip holds ~1.7 GHz, not the 2.4 GHz behind the 2.5 PFLOP/s figure
+                    "frac_of_device_mfma_loop": (ach / 1e12 / clock["mfma_loop_tflops"]) if (clock and d != DOMINANT_FP8) else None,
                     "conv_linear_class": {"kernels": [K_NAMES[c] for c in GEMM_CLASSES], "achieved": cls_fl / (cls_ms * 1e-3) / 1e12,
                                           "frac": cls_fl / (cls_ms * 1e-3) / peak, "launches_timed": int(cls_n)}}
 
