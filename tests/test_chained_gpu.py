@@ -6,8 +6,8 @@ nothing failed if the chained bf16 / fp8 drift doubled.  Here BASELINE config 1'
 batch (same synthetic weights as bench.py).  The reference has no bf16 / fp8 path, so the bars are this package's stated
 tolerances, relative to max|final latent| of the f32 mode:
 
-    per-forward (first step's guided-free eps, cond/uncond batch): bf16 <= 2e-2, fp8 <= 8e-2     (as test_model_gpu /
-                                                                                                  test_fp8_gpu state)
+    per-forward (first step's eps, cond half): bf16 <= 3e-2 (max-abs, as test_model_gpu's BF16_FWD_BAR), fp8 <= 8e-2
+                                               (as test_fp8_gpu states)
     final latent after the chain:                                  bf16 <= 3e-2, fp8 <= 1e-1
     and, derived from the measured per-forward error e1 of the same run:  final <= CHAIN_GAIN * e1  (the chain may not
     amplify the per-forward error by more than the stated gain; measured gains are written to parity_report.txt)
@@ -26,7 +26,7 @@ sys.path.insert(0, str(ROOT))
 
 pytestmark = pytest.mark.gpu
 
-FWD_BAR = {"bf16": 2e-2, "fp8": 8e-2}
+FWD_BAR = {"bf16": 3e-2, "fp8": 8e-2}
 FINAL_BAR = {"bf16": 3e-2, "fp8": 1e-1}
 CHAIN_GAIN = 2.5
 
