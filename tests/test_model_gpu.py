@@ -369,6 +369,36 @@ def test_sd15_unet_new_fused_paths_ab(gpu, report, knobs):
         _assert_bf16_ab(report, f"sd15_unet Bf=16 with (A) / without (B) {knob}", full, out, ref)
 
 
+@pytest.mark.parametrize("B,H,W", [(16, 48, 48), (6, 96, 64), (3, 40, 24)])
+def test_sd15_unet_other_latent_sizes(gpu, report, B, H, W):
+    """Latent sizes other than the benchmark's 64 x 64 (the planner's fall-backs: 48 x 48 -> 2304 pixels per sample, row-panel
+    launches and the GroupNorm-in-prologue path but no LDS-halo convolution (Wo = 48); 96 x 64 -> halo rows of a non
+    power-of-two image height; 40 x 24 with an odd batch -> below every row-panel threshold, ragged query blocks in the
+    short-key attention): the bf16 forward against the f32-mode forward of the same batch, per-forward bars."""
+    from adaface_amd.engine import Engine
+    from adaface_amd.synth import synth_weights_into
+    cfg = O.SD15_UNET
+    g = torch.Generator().manual_seed(H * W + B)
+    x = torch.randn(B, 4, H, W, generator=g).to(gpu)
+    t = torch.randint(0, 1000, (B,), generator=g).to(gpu)
+    ctx = torch.randn(B * 16, 77, cfg.context_dim, generator=g).to(gpu)
+    out = {}
+    for dtype in ("f32", "bf16"):
+        eng = Engine(dtype=dtype, unet=_unet_kwargs(cfg))
+        synth_weights_into(eng, O.unet_param_shapes(cfg), seed=71, device=gpu)
+        eng.set_context(ctx, B, layerwise=True)
+        out[dtype] = eng.unet_forward(x, t)
+        again = eng.unet_forward(x, t)
+        assert torch.equal(out[dtype], again)                 # run-to-run determinism at this shape
+        eng.close()
+    scale = out["f32"].abs().max().item()
+    e = (out["bf16"] - out["f32"]).abs().max().item() / scale
+    r = _rms_rel(out["bf16"], out["f32"])
+    report(f"sd15_unet B={B} {H}x{W} bf16 forward vs f32 mode", e, scale, BF16_FWD_BAR)
+    report(f"sd15_unet B={B} {H}x{W} bf16 forward vs f32 mode, rms / rms", r, 1.0, BF16_FWD_RMS_BAR)
+    assert torch.isfinite(out["bf16"]).all() and e <= BF16_FWD_BAR and r <= BF16_FWD_RMS_BAR, (e, r)
+
+
 def test_sd15_unet_batch_consistency(gpu, report):
     """f32 mode: Bf = 16 vs Bf = 2 pairs agree to 1e-5 (summation order only).  bf16 mode: two tilings round their
     activations differently; the Bf = 16 forward and every Bf = 2 pair are held to the per-forward bar against the
