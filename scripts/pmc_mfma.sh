@@ -4,7 +4,7 @@
 # usage: scripts/pmc_mfma.sh  -> gpurun_out/mfma_util.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/mf; mkdir -p gpurun_out/mf
-RE="conv_gemm_pp_kernel|conv_gemm_kernel|conv3x3_halo8_kernel|rowpanel_kernel|attn_kernel|attn_ring40_kernel"
+RE="conv_gemm_pp_kernel|conv_gemm_kernel|conv3x3_halo8_kernel|rowpanel_kernel|attn_kernel|attn_ring40_kernel|xattn_short_kernel"
 for k in conv linear attn; do
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --kernel-include-regex "$RE" --output-format csv -d gpurun_out/mf/$k -- python scripts/bench_shapes.py --only $k --reps 1 > gpurun_out/mf/$k.txt 2>&1 || exit 1
 done
