@@ -99,6 +99,8 @@ struct AfKnobs {
                             //                         after each), 1 = block-ordered compute phase, 2 = merged (no staging phase)
   int attn_short;           // AF_ATTN_SHORT           0 = cross-attention (<= 96 keys) stays on the flash kernels
   int rowpanel_deep;        // AF_ROWPANEL_DEEP        0 = row-panel kernels keep the round-2 weight ring (3 slots, prefetch distance 2)
+  int gn_reduce;            // AF_GN_REDUCE            0 = a sliced-K convolution always launches its own reduce (never left to the
+                            //                         single-launch GroupNorm that follows it)
   int gn_consumer;          // AF_GN_CONSUMER          0 = the SpatialTransformer's GroupNorm always runs its own apply pass (never
                             //                         in the prologue of a row-panel proj_in)
 };
@@ -314,6 +316,9 @@ struct ConvGemmParams {
   // would have stored
   const float* gn_ab;
   int gn_hw;
+  // split-K launch whose slabs the CONSUMER reduces (a single-launch GroupNorm, af_launch_groupnorm_slabs): no reduce launch,
+  // p.out is not written
+  int defer_reduce;
 };
 
 struct AfGemmPlan {

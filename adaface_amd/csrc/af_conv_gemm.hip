@@ -2358,7 +2358,8 @@ int af_launch_cast_fp8(const void* x, void* y, long n, float mul, hipStream_t st
 }
 
 AfGemmPlan g_af_last_plan = {0, 1, 0, 0, 1};
-long g_af_gn_consumer_launches = 0;   // row-panel launches that applied the GroupNorm of their input themselves
+long g_af_gn_consumer_launches = 0;
+long g_af_deferred_reduces = 0;       // sliced-K launches whose reduce was left to the GroupNorm that consumes them   // row-panel launches that applied the GroupNorm of their input themselves
 // launches since af_gemm_plan_counts_reset: [0..5] by tile (implicit-GEMM / ping-pong kernels), [6] LDS-halo kernel,
 // [7] launches that sliced K (counted in their tile's slot as well), [8] / [9] ping-pong launches with the LayerNorm
 // consumer / statistics-producer epilogue, [10] ping-pong launches with fp8 operands, [11] eight-wave halo launches
@@ -2847,6 +2848,11 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   }
   AfGemmPlan pl = plan ? *plan : af_plan_conv_gemm(p, batch, (int)sizeof(T));
   if (pl.splitk > 1 && !ws) pl.splitk = 1;  // no workspace supplied: fall back to one slice
+  if (p.defer_reduce && (pl.splitk <= 1 || p.residual || batch != 1 || p.epilogue != AF_EPI_NONE || p.ln_stats || p.ln_stats_out || p.gn_stats_out)) {
+    af_set_error_msg("conv_gemm: defer_reduce on a launch that does not slice K (or carries a residual / fused epilogue)");
+    return -1;
+  }
+  if (p.defer_reduce) g_af_deferred_reduces += 1;
   p.splitk = pl.splitk;
   p.ws = ws;
   g_af_last_plan = pl;
@@ -2913,7 +2919,7 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
       return -1;
     }
     if (rc) return rc;
-    if (p.splitk > 1) {
+    if (p.splitk > 1 && !p.defer_reduce) {
       const long nq = (long)p.M * (p.N >> 2);
       unsigned blocks = (unsigned)((nq + 255) / 256);
       if (blocks > 4096) blocks = 4096;
@@ -2944,7 +2950,7 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
     default: rc = launch_cfg<T, 64, 64>(p, batch, stream); break;
   }
   if (rc) return rc;
-  if (p.splitk > 1) {
+  if (p.splitk > 1 && !p.defer_reduce) {
     const long nq = (long)p.M * (p.N >> 2);
     unsigned blocks = (unsigned)((nq + 255) / 256);
     if (blocks > 4096) blocks = 4096;

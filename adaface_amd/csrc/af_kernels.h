@@ -20,6 +20,15 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
                         const float* beta, float eps, int silu, void* y, long y_bs, int ldy, void* workspace,
                         hipStream_t stream, float fp8_mul = 0.f,    // fp8_mul != 0: y is e4m3 bytes of result * fp8_mul
                         const float* pre_partial = nullptr, int pre_npart = 0);   // statistics already summed by the producer
+// GroupNorm (+SiLU) of a convolution output left as fp32 split-K slabs ws[splitk][M][N] (ConvGemmParams::defer_reduce): the
+// single-launch kernel forms every element as splitk_reduce_kernel would have stored it; af_gn_small_ok says whether a shape
+// has that kernel
+bool af_gn_small_ok(int HW, int Cn, int elem_size);
+template <typename T>
+int af_launch_groupnorm_slabs(const float* ws, int splitk, int M, int N, const float* bias, const void* rowbias, int ldrb, int B,
+                              int HW, int Cn, const float* gamma, const float* beta, float eps, int silu, void* y, long y_bs,
+                              int ldy, hipStream_t stream, float fp8_mul = 0.f);
+extern long g_af_deferred_reduces;
 // GroupNorm reduced to its per-sample affine map ab_out [B][2][Cn] (scale, shift) for a consumer that applies it itself
 // (ConvGemmParams::gn_ab): statistics pass (unless pre_partial) + fold, no pass that writes the normalised tensor
 template <typename T>

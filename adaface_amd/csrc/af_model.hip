@@ -55,7 +55,7 @@ AfKnobs g_af_knobs = {
     knob_env("AF_LN_FUSE", 1),         knob_env("AF_GEGLU_ROWPANEL", 4), knob_env("AF_CONV_HALO8", 1), knob_env("AF_CONV_FAST_TAPS", 1),
     knob_env("AF_PP_STAGGER", 1),      knob_env("AF_GN_PRODUCER", 1),     knob_env("AF_CONV_UP_PHASE4", 1),
     knob_env("AF_PP_SCHED", 2),        knob_env("AF_ATTN_SHORT", 1),      knob_env("AF_ROWPANEL_DEEP", 1),
-    knob_env("AF_GN_CONSUMER", 1)};
+    knob_env("AF_GN_REDUCE", 1),       knob_env("AF_GN_CONSUMER", 1)};
 static const AfKnobs g_af_knobs_initial = g_af_knobs;
 static int* knob_slot(const char* name) {
   static const struct { const char* n; int AfKnobs::*m; } tab[] = {
@@ -66,7 +66,7 @@ static int* knob_slot(const char* name) {
       {"gn_small", &AfKnobs::gn_small}, {"gn_fold", &AfKnobs::gn_fold}, {"conv_tap_inner", &AfKnobs::conv_tap_inner}, {"ln_fuse", &AfKnobs::ln_fuse},
       {"geglu_rowpanel", &AfKnobs::geglu_rowpanel}, {"conv_halo8", &AfKnobs::conv_halo8}, {"conv_fast_taps", &AfKnobs::conv_fast_taps}, {"pp_stagger", &AfKnobs::pp_stagger}, {"gn_producer", &AfKnobs::gn_producer}, {"conv_up_phase4", &AfKnobs::conv_up_phase4}, {"pp_sched", &AfKnobs::pp_sched},
       {"attn_short", &AfKnobs::attn_short}, {"rowpanel_deep", &AfKnobs::rowpanel_deep},
-      {"gn_consumer", &AfKnobs::gn_consumer}};
+      {"gn_reduce", &AfKnobs::gn_reduce}, {"gn_consumer", &AfKnobs::gn_consumer}};
   if (!name) return nullptr;
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) return &(g_af_knobs.*(t.m));
@@ -151,6 +151,13 @@ struct Act {  // NHWC activation view
   // gn_stats_out); valid for exactly the B samples and C channels of this view
   const float* gn_part = nullptr;
   int gn_npart = 0;
+  // the tensor exists only as the fp32 split-K slabs of the convolution that produces it (ConvGemmParams::defer_reduce): the
+  // one consumer, a single-launch GroupNorm, sums them (slab_k slices of [npix][C], + bias, + per-sample row bias)
+  const float* slabs = nullptr;
+  int slab_k = 0;
+  const float* slab_bias = nullptr;
+  const void* slab_rowbias = nullptr;
+  int slab_ldrb = 0;
   long npix() const { return (long)B * H * W; }
 };
 
@@ -874,10 +881,13 @@ struct Runner {
   }
   // want_gn: 1 = also write the GroupNorm partial sums of `out` into the arena (consumer inside the caller's arena scope),
   // 2 = into the handle's carry buffer (consumer = the next layer); out.gn_part is set when the launch can do it
+  // defer_ok: the caller's ONLY consumer of `out` is a GroupNorm that af_gn_small_ok says runs as the single-launch kernel: a
+  // launch that slices K then leaves its slabs un-reduced (out.slabs) and `out`'s buffer is never written
   int conv(const Linear& L, const Act& x, Act& out, int stride, int up, const Act* residual, const void* rowbias,
-           int ldrb, int n_valid = -1, int pad = -1, const LnArgs* ln = nullptr, int want_gn = 0) {
+           int ldrb, int n_valid = -1, int pad = -1, const LnArgs* ln = nullptr, int want_gn = 0, bool defer_ok = false) {
     AF_TRY(check(out));
     out.gn_part = nullptr; out.gn_npart = 0;
+    out.slabs = nullptr; out.slab_k = 0;
     ConvGemmParams p;
     conv_params(p, L, x, out, stride, up, residual, rowbias, ldrb, n_valid, pad);
     bool ln_parts_pending = false;
@@ -932,10 +942,20 @@ struct Runner {
     }
     void* ws = nullptr;
     if (pl.splitk > 1) {
+      const bool defer = defer_ok && g_af_knobs.gn_reduce && !x.f8 && !residual && !ln && out.C == p.N && L.ks * L.ks * L.cin_pad == p.K &&
+                         af_gn_small_ok(out.H * out.W, out.C, (int)esize(dt));
       const size_t mk = A.mark();
       ws = A.alloc(pl.ws_bytes);  // consumed by the reduce kernel enqueued in this call; later allocations
-      A.release(mk);              // are only touched by later (stream-ordered) kernels
-      if (!ws) { af_set_error_msg("arena exhausted (split-K slabs)"); return AF_ERR_STATE; }
+      if (!defer) A.release(mk);  // are only touched by later (stream-ordered) kernels -- unless the consumer reduces:
+      if (!ws) { af_set_error_msg("arena exhausted (split-K slabs)"); return AF_ERR_STATE; }   // then they live on in the caller's scope
+      if (defer) {
+        p.defer_reduce = 1;
+        out.slabs = reinterpret_cast<const float*>(ws);
+        out.slab_k = pl.splitk;
+        out.slab_bias = p.bias;
+        out.slab_rowbias = p.rowbias;
+        out.slab_ldrb = p.ldrb;
+      }
     }
     if (dry) return 0;
     return DISPATCH(dt, af_launch_conv_gemm<bf16>(p, 1, s, &pl, ws), af_launch_conv_gemm<float>(p, 1, s, &pl, ws));
@@ -951,6 +971,17 @@ struct Runner {
     if (!ws) { af_set_error_msg("arena exhausted (groupnorm workspace)"); return AF_ERR_STATE; }
     if (dry) return 0;
     if (x.C != N.C) { af_set_error_msg("groupnorm: C mismatch %d vs %d", x.C, N.C); return AF_ERR_INVALID; }
+    if (x.slabs) {   // x was never materialised: reduce its producer's split-K slabs on the way in
+      const float f8 = y.f8 ? (float)(1 << AF_FP8_ACT_SHIFT) : 0.f;
+      if (y.f8)
+        return af_launch_groupnorm_slabs<bf16>(x.slabs, x.slab_k, (int)x.npix(), x.C, x.slab_bias, x.slab_rowbias, x.slab_ldrb, x.B, HW,
+                                               x.C, N.gamma, N.beta, N.eps, silu, y.p, (long)HW * y.ld, y.ld, s, f8);
+      return DISPATCH(dt,
+                      af_launch_groupnorm_slabs<bf16>(x.slabs, x.slab_k, (int)x.npix(), x.C, x.slab_bias, x.slab_rowbias, x.slab_ldrb, x.B,
+                                                      HW, x.C, N.gamma, N.beta, N.eps, silu, y.p, (long)HW * y.ld, y.ld, s, 0.f),
+                      af_launch_groupnorm_slabs<float>(x.slabs, x.slab_k, (int)x.npix(), x.C, x.slab_bias, x.slab_rowbias, x.slab_ldrb, x.B,
+                                                       HW, x.C, N.gamma, N.beta, N.eps, silu, y.p, (long)HW * y.ld, y.ld, s, 0.f));
+    }
     // (statistics already summed by the convolution that produced x: no pass over the tensor for them)
     const float* pre = g_af_knobs.gn_producer ? x.gn_part : nullptr;
     if (y.f8)
@@ -1006,7 +1037,9 @@ static int run_resblock(Runner& R, const ResBlockW& w, const Act& x, Act& out, c
   AF_TRY(R.groupnorm(w.n1, x, t1, 1));
   const void* rb = (emb_all && w.emb_off >= 0) ? R.elem_ptr(const_cast<void*>(emb_all), w.emb_off) : nullptr;
   // (conv1 also sums the GroupNorm statistics of its output where its kernel can: n2 then makes no pass for them)
-  AF_TRY(R.conv(w.c1, t1, t2, 1, 0, nullptr, rb, emb_ld, -1, -1, nullptr, 1));
+  // (... and where it slices K and n2 is the single-launch small-map kernel, n2 reduces the slabs itself: t2 is then never
+  // written -- its only reader is n2)
+  AF_TRY(R.conv(w.c1, t1, t2, 1, 0, nullptr, rb, emb_ld, -1, -1, nullptr, 1, true));
   Act t3 = R.fp8_capable(w.c2, t2, out) ? R.alloc_act8(x.B, x.H, x.W, w.cout) : R.alloc_act(x.B, x.H, x.W, w.cout);
   AF_TRY(R.groupnorm(w.n2, t2, t3, 1));
   Act sk = x;
@@ -2264,6 +2297,7 @@ int af_gemm_plan_counts(int64_t* counts10) {
 int af_gemm_plan_counts_reset(void) {
   g_af_attn_short_launches = 0;
   g_af_gn_consumer_launches = 0;
+  g_af_deferred_reduces = 0;
   for (int i = 0; i < 15; ++i) g_af_plan_counts[i] = 0;
   return AF_OK;
 }
@@ -2274,6 +2308,7 @@ int64_t af_up_phase4_launches(void) { return g_af_plan_counts[13]; }
 int64_t af_gn_producer_launches(void) { return g_af_plan_counts[14]; }
 int64_t af_attn_short_launches(void) { return g_af_attn_short_launches; }
 int64_t af_gn_consumer_launches(void) { return g_af_gn_consumer_launches; }
+int64_t af_deferred_reduces(void) { return g_af_deferred_reduces; }
 int af_set_fp8(af_handle* h, int on) {
   if (!h) { af_set_error_msg("af_set_fp8: null handle"); return AF_ERR_INVALID; }
   if (on && h->dtype != AF_DTYPE_BF16) { af_set_error_msg("af_set_fp8: the fp8 convolutions extend the bf16 mode (handle is f32)"); return AF_ERR_STATE; }

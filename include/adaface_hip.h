@@ -244,6 +244,8 @@ int64_t af_gn_producer_launches(void); /* convolutions that also wrote the Group
 int64_t af_attn_short_launches(void);
 /* row-panel GEMM launches that applied the GroupNorm of their input in their prologue (SpatialTransformer.norm + proj_in) */
 int64_t af_gn_consumer_launches(void);
+/* sliced-K convolutions whose fp32 slabs were reduced by the single-launch GroupNorm that consumes them (no reduce launch) */
+int64_t af_deferred_reduces(void);
 int64_t af_up_phase4_launches(void); /* upsampled 3x3 convolutions run as four 2x2 phase convolutions on the stored map */
 int64_t af_rowpanel_launches(void); /* launches of the row-panel kernels (K = 320 / 640 / 1280 GEMMs with the activation rows resident in registers) */
 int af_op_conv2d_fp8(const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev, float* y_dev,
