@@ -55,7 +55,7 @@ AfKnobs g_af_knobs = {
     knob_env("AF_LN_FUSE", 1),         knob_env("AF_GEGLU_ROWPANEL", 4), knob_env("AF_CONV_HALO8", 1), knob_env("AF_CONV_FAST_TAPS", 1),
     knob_env("AF_PP_STAGGER", 1),      knob_env("AF_GN_PRODUCER", 1),     knob_env("AF_CONV_UP_PHASE4", 1),
     knob_env("AF_PP_SCHED", 2),        knob_env("AF_ATTN_SHORT", 1),      knob_env("AF_ROWPANEL_DEEP", 1),
-    knob_env("AF_GN_REDUCE", 1),       knob_env("AF_GN_CONSUMER", 1)};
+    knob_env("AF_GN_REDUCE", 0),       knob_env("AF_GN_CONSUMER", 1)};
 static const AfKnobs g_af_knobs_initial = g_af_knobs;
 static int* knob_slot(const char* name) {
   static const struct { const char* n; int AfKnobs::*m; } tab[] = {

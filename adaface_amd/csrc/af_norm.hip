@@ -355,10 +355,20 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x, 
         float acc[EPC];
 #pragma unroll
         for (int t = 0; t < EPC / 4; ++t) {
-          float4 s4 = *reinterpret_cast<const float4*>(src.ws + m * src.N + n + 4 * t);
-          for (int zz = 1; zz < src.splitk; ++zz) {
-            const float4 b4 = *reinterpret_cast<const float4*>(src.ws + ((long)zz * src.M + m) * src.N + n + 4 * t);
-            s4.x += b4.x; s4.y += b4.y; s4.z += b4.z; s4.w += b4.w;
+          // slices in groups of eight: all loads of a group are issued before the first add (same summation order)
+          const float* base = src.ws + m * src.N + n + 4 * t;
+          const long zs = (long)src.M * src.N;
+          float4 s4 = float4{0.f, 0.f, 0.f, 0.f};
+          for (int z0 = 0; z0 < src.splitk; z0 += 8) {
+            float4 part[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              part[u] = z0 + u < src.splitk ? *reinterpret_cast<const float4*>(base + (z0 + u) * zs) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              if (z0 + u == 0) s4 = part[0];
+              else if (z0 + u < src.splitk) { s4.x += part[u].x; s4.y += part[u].y; s4.z += part[u].z; s4.w += part[u].w; }
+            }
           }
           acc[4 * t] = s4.x; acc[4 * t + 1] = s4.y; acc[4 * t + 2] = s4.z; acc[4 * t + 3] = s4.w;
           if (src.bias) {
