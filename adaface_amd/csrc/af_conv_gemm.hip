@@ -2440,6 +2440,13 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
       if (s >= 2) pl.splitk = s;
     }
   }
+  // few rows, short K (the 8x8-level transformer GEMMs [1024, 1280] -> 1280 / 3840, the time-embedding GEMMs with M = Bf): these
+  // launches are latency-bound, and 64 x 64 tiles in ONE K slice (a few hundred small workgroups, no slabs, no reduce launch)
+  // measure ahead of the 128 x 128 tile over two slices the cost model picks: 23.2 -> 18.9 us and 22.7 -> 18.9 us
+  if (g_af_knobs.small_m_tile64 && batch == 1 && !geglu && p.M <= 1024 && p.N % 64 == 0 && KT <= 32) {
+    const long nb64 = (long)((p.M + 63) / 64) * (p.N / 64);
+    if (nb64 >= 64 && nb64 <= 1024) { pl.tile = 3; pl.splitk = 1; }
+  }
   // 3x3 / stride 1 / no upsample on maps that tile by 4x32 or 8x16 pixels: LDS-halo kernel (tile 2 or 0 = BN 64 / 128)
   pl.halo_tw = 0;
   if (p.ks == 3 && p.stride == 1 && p.up == 0 && p.pad == 1 && batch == 1 && !geglu && pl.splitk == 1 &&
