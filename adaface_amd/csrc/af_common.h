@@ -99,6 +99,7 @@ struct AfKnobs {
                             //                         after each), 1 = block-ordered compute phase, 2 = merged (no staging phase)
   int attn_short;           // AF_ATTN_SHORT           0 = cross-attention (<= 96 keys) stays on the flash kernels
   int rowpanel_deep;        // AF_ROWPANEL_DEEP        0 = row-panel kernels keep the round-2 weight ring (3 slots, prefetch distance 2)
+  int gemm_m128;            // AF_GEMM_M128            0 = no 128 x 160 tile GEMM for the few-row plain GEMMs (16x16 level)
   int small_m_tile64;       // AF_SMALL_M_TILE64       0 = GEMMs with <= 1024 rows and K <= 2048 keep the cost model's tile / K slices
   int gn_reduce;            // AF_GN_REDUCE            1 = a sliced-K ResBlock conv1 on a small map leaves its reduce to the single-launch
                             //                         GroupNorm that follows it.  Default 0: bit-identical, but measured 0.1 ms per forward

@@ -1991,6 +1991,214 @@ static int launch_plain_rowpanel(const ConvGemmParams& p, hipStream_t stream, bo
 }
 
 // ---------------------------------------------------------------------------
+// 128 x 160 tile GEMM for FEW rows (round 3): the plain 1x1 GEMMs of the 16x16 level, [4096, 1280] -> 1280 (25 per forward).
+//
+// 4096 rows are sixteen 256-row tiles: the 256 x 160 ping-pong tile leaves half of the chip idle (128 workgroups, 30 us) and
+// the K = 1280 row-panel form fills it only by having eight workgroups re-load each 128-row panel into registers (320 KB per
+// workgroup in fragment-shaped 16-byte loads: its texture-address FIFO is full 13-16 % of the time, 28 us).  Here a workgroup
+// owns 128 rows x 160 columns (32 x 8 = 256 workgroups), BOTH operands stream through a four-slot LDS ring in whole 128-byte
+// lines by LDS-DMA (16 + 20 pieces of 1 KiB per K step, 4-5 per wave), prefetch distance three steps, one barrier per step;
+// eight waves as 2 column halves x 4 row quarters, 32 rows x 80 columns each (2 x 5 MFMA 16x16x32 blocks, 20 MFMAs per
+// step).  Swizzle, fragment addressing and the transposed epilogue are those of rowpanel_kernel.
+// ---------------------------------------------------------------------------
+template <int D_> struct M128CfgT {
+  static constexpr int BM = 128, BN = 160, D = D_, NS = D + 1;
+  static constexpr int XBYTES = BM * 128, WBYTES = BN * 128, SLOT = XBYTES + WBYTES;     // 16 + 20 KiB
+  static constexpr int XP = BM / 8, WP = BN / 8;                                         // 16 + 20 pieces per step
+  static constexpr int NI = 5, MJ = 2;                                                    // 16-wide blocks per wave: 80 columns, 32 rows
+  static constexpr int OCOLS = 80, OPITCH = OCOLS * 2 + 16, OBYTES = 32 * OPITCH;         // per-wave output transposition tile
+  static constexpr int CPR = OCOLS / 8, NST = 32 * CPR / 64;                              // 10 chunks per row segment, 5 stores per lane
+  // output tiles behind the ring while both fit (D = 2: 108 + 44 KiB), else in the ring's first slots after the last step
+  static constexpr bool OWN_OTILE = NS * SLOT + 8 * OBYTES <= 160 * 1024;
+  static constexpr int OTILE0 = OWN_OTILE ? NS * SLOT : 0;
+  static constexpr int LDS_BYTES = OWN_OTILE ? NS * SLOT + 8 * OBYTES : NS * SLOT;
+  static_assert(LDS_BYTES <= 160 * 1024 && 8 * OBYTES <= NS * SLOT && (32 * CPR) % 64 == 0, "m128 LDS / store mapping");
+};
+
+template <bool RES, int DEPTH>
+__global__ __launch_bounds__(512) void gemm_m128_kernel(const ConvGemmParams p) {
+  using C = M128CfgT<DEPTH>;
+  typedef bf16 T;
+  constexpr int NI = C::NI, MJ = C::MJ, D = C::D, NS = C::NS, NST = C::NST, CPR = C::CPR;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wid >> 2, wq = wid & 3;
+  const int ntm = p.M / C::BM, ntn = p.N / C::BN;
+  int tm, tn;
+  tile_coords(blockIdx.x, gridDim.x, ntm, ntn, p.group_m, tm, tn);
+  const int m0 = tm * C::BM, n0 = tn * C::BN;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(reinterpret_cast<const T*>(p.src)), 0, (int)0xFFFFFFF0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(reinterpret_cast<const T*>(p.W)), 0, (int)0xFFFFFFF0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(p.out), 0, (int)0xFFFFFFF0u, 0x00020000);
+
+  // ---- staging: piece = 8 rows x 128 B; lane -> row lane >> 3, LDS slot lane & 7 <- data chunk (lane & 7) ^ row (the swizzle
+  // lives in the SOURCE address).  Activations: pieces wid, wid + 8 (all waves two); weights: wid, wid + 8, and wid + 16 for
+  // waves 0-3 (20 pieces) ----
+  const int srow = lane >> 3;
+  const unsigned dchunk = (unsigned)((lane & 7) ^ srow);
+  unsigned x_off[2], w_off[3];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int m = m0 + (wid + 8 * q) * 8 + srow;
+    x_off[q] = m < p.M ? (unsigned)((long)m * p.ldc * 2) + dchunk * 16u : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int n = n0 + (wid + 8 * q) * 8 + srow;
+    w_off[q] = (n < p.Wrows && wid + 8 * q < C::WP) ? (unsigned)((long)n * p.ldw * 2) + dchunk * 16u : 0xFFFFFFFFu;
+  }
+  const int nwq = wid < 4 ? 3 : 2;                  // weight pieces of this wave per step (vmcnt: + 2 activation pieces)
+  const int KT = p.K / 64;
+  // (steps past the end are not staged; the tail of the loop waits for everything outstanding instead of counting)
+  auto stage = [&](int t, int slot) {               // (by value: see KWalk in conv_gemm_pp_kernel)
+    if (t >= KT) return;
+    const unsigned so = (unsigned)t * 128u;
+    char* base = smem + slot * C::SLOT;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) lds_dma16(rs_x, base + (wid + 8 * q) * 1024, x_off[q], so);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (q < 2 || wid < 4) lds_dma16(rs_w, base + C::XBYTES + (wid + 8 * q) * 1024, w_off[q], so);
+  };
+
+  // ---- fragment addressing (rows of 128 B; 16-byte chunk c of row r sits in slot c ^ (r & 7)) ----
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) char*)smem);
+  const unsigned fch0 = (unsigned)((lane >> 4) ^ (lane & 7)) * 16u;
+  const unsigned fch1 = (unsigned)(((lane >> 4) + 4) ^ (lane & 7)) * 16u;
+  const unsigned x_base = (unsigned)((wq * 32 + (lane & 15)) * 128);                   // + j * 2048
+  const unsigned w_base = (unsigned)(C::XBYTES + (g * 80 + (lane & 15)) * 128);        // + i * 2048
+  const int cl = 4 * (lane >> 4);
+
+  f32x4 acc[NI][MJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  pp_u32x4 xf[MJ][2], wf[NI][2];
+  auto wait_block = [&](auto nc, pp_u32x4 (&blk)[2]) {
+    constexpr int n = decltype(nc)::value;
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(blk[0]), "+v"(blk[1]) : "n"(n) : "memory");
+  };
+  // one K step: the two activation blocks and the first weight block are read first; weight block i + 2 is read behind the
+  // MFMAs of block i; the LDS-DMA of step t + D is issued behind the second weight block's MFMAs
+  auto step = [&](int slot, int t, int stage_slot) {
+    const unsigned sb = lds0 + (unsigned)(slot * C::SLOT);
+    auto rd_x = [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      xf[j][0] = pp_lds_read128<j * 2048>(sb + x_base + fch0);
+      xf[j][1] = pp_lds_read128<j * 2048>(sb + x_base + fch1);
+    };
+    auto rd_w = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      wf[i][0] = pp_lds_read128<i * 2048>(sb + w_base + fch0);
+      wf[i][1] = pp_lds_read128<i * 2048>(sb + w_base + fch1);
+    };
+    rd_x(std::integral_constant<int, 0>{});
+    rd_x(std::integral_constant<int, 1>{});
+    rd_w(std::integral_constant<int, 0>{});
+    rd_w(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    pp_static_for<0, NI>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      // reads outstanding behind block i's: the blocks issued after it (two ahead, until the last ones)
+      constexpr int issued = (i + 2) < NI ? (i + 2) : NI;          // weight blocks issued before block i's MFMAs
+      wait_block(std::integral_constant<int, 2 * (issued - i - 1)>{}, wf[i]);
+      if constexpr (i == 0) { wait_block(std::integral_constant<int, 2 * (issued - 1)>{}, xf[0]); wait_block(std::integral_constant<int, 2 * (issued - 1)>{}, xf[1]); }
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i][0]), __builtin_bit_cast(bf16x8, xf[j][0]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i][1]), __builtin_bit_cast(bf16x8, xf[j][1]), acc[i][j], 0, 0, 0);
+        asm volatile("" : "+v"(acc[i][j]));
+      }
+      if constexpr (i + 2 < NI) rd_w(std::integral_constant<int, i + 2>{});
+      if constexpr (i == 1) stage(t + D, stage_slot);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    pp_wait_lgkm0();
+  };
+
+  // ---- main loop: step t in slot t % NS; steps 0 .. D-1 in flight ----
+#pragma unroll
+  for (int i = 0; i < D; ++i) stage(i, i);
+  int cur = 0;
+  for (int t = 0; t < KT; ++t) {
+    // own pieces of step t landed: everything but the pieces of the next D - 1 steps (2 + nwq per step); in the last D - 1
+    // steps fewer are in flight: wait for all of them
+    if (t + D > KT) pp_wait_vm<0>();
+    else if (nwq == 3) pp_wait_vm<5 * (D - 1)>(); else pp_wait_vm<4 * (D - 1)>();
+    __builtin_amdgcn_s_barrier();
+    const int prev = cur == 0 ? NS - 1 : cur - 1;
+    step(cur, t, prev);
+    cur = cur + 1 == NS ? 0 : cur + 1;
+  }
+  pp_wait_vm<0>();
+  __builtin_amdgcn_s_barrier();   // every wave has read its last step: the ring is free for the output tiles
+  asm volatile("" ::: "memory");  // (s_barrier is no memory operation for hipcc: keeps the tile stores below it)
+
+  // ---- epilogue: bias (+ residual) in the accumulator layout, bf16 through the wave-private tile, 16-byte row stores ----
+  char* otile = smem + C::OTILE0 + wid * C::OBYTES;
+  const int r0 = m0 + wq * 32, ncol = n0 + g * 80;
+  float4 bvec[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+    bvec[i] = p.bias ? *reinterpret_cast<const float4*>(p.bias + ncol + i * 16 + cl) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    const int m = r0 + j * 16 + (lane & 15);
+    const bool mok = m < p.M;
+    Quad<T> rq[RES ? NI : 1];
+    if constexpr (RES) {
+      const T* rp = reinterpret_cast<const T*>(p.residual) + (long)(mok ? m : 0) * p.ldr + ncol + cl;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) rq[i].load(rp + i * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float* bp = reinterpret_cast<const float*>(&bvec[i]);
+      Quad<T> o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[i][j][e] * p.alpha + bp[e];
+        if constexpr (RES) v += to_f32<T>(rq[i].e[e]);
+        o.e[e] = from_f32<T>(v);
+      }
+      o.store(reinterpret_cast<T*>(otile + (j * 16 + (lane & 15)) * C::OPITCH) + i * 16 + cl);
+    }
+  }
+  // All chunks and offsets first, then the stores back to back with nothing between them: a 16-byte buffer store whose data
+  // register a VALU instruction rewrites in the next slot was seen to store the NEW value on gfx950 (hipcc pads that hazard only
+  // for stores without an SGPR offset, and this one has ncol * 2 there).
+  pp_u32x4 ov[NST];
+  unsigned ooff[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int c = lane + 64 * i;
+    const int row = c / CPR, ch = c - row * CPR;
+    const int m = r0 + row;
+    ov[i] = *reinterpret_cast<const pp_u32x4*>(otile + row * C::OPITCH + ch * 16);
+    ooff[i] = m < p.M ? (unsigned)((long)m * p.ldo * 2) + (unsigned)ch * 16u : 0xFFFFFFFFu;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NST; ++i) __builtin_amdgcn_raw_buffer_store_b128(ov[i], rs_o, ooff[i], ncol * 2, 0);
+}
+
+template <bool RES, int DEPTH> static int launch_gemm_m128_one(const ConvGemmParams& p, hipStream_t stream) {
+  using C = M128CfgT<DEPTH>;
+  static unsigned long long attr_done = 0;
+  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&gemm_m128_kernel<RES, DEPTH>), C::LDS_BYTES)) return rc;
+  dim3 grid((p.M / C::BM) * (p.N / C::BN), 1, 1);
+  hipLaunchKernelGGL((gemm_m128_kernel<RES, DEPTH>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+static int launch_gemm_m128(const ConvGemmParams& p, hipStream_t stream) {
+  return p.residual ? launch_gemm_m128_one<true, 2>(p, stream) : launch_gemm_m128_one<false, 2>(p, stream);
+}
+
+// ---------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with an LDS-resident input halo.
 //
 // The implicit-GEMM kernel above re-gathers every input pixel 9 times (once per filter tap); at the 64x64 and
@@ -2786,7 +2994,8 @@ bool af_conv_gn_stats_ok(const ConvGemmParams& p, const AfGemmPlan& pl, int cpg)
 
 // Which row-panel kernel a bf16 launch with these (validated) parameters takes in ONE K slice: 0 none, 1 GEGLU K = 320,
 // 2 plain K = 320 (LayerNorm consumer / producer, residual), 3 plain K = 1280 -> 1280, 4 GEGLU K = 640, 5 plain K = 640
-// (N >= 1920).  The model asks before it decides who finalises LayerNorm statistics (ConvGemmParams::ln_parts_n).
+// (N >= 1920), 6 the 128 x 160 tile GEMM for few rows (not a row-panel kernel: LayerNorm / GroupNorm consumers never get it).
+// The model asks before it decides who finalises LayerNorm statistics (ConvGemmParams::ln_parts_n).
 int af_conv_rowpanel_kind(const ConvGemmParams& p, int batch) {
   const int lvl = g_af_knobs.geglu_rowpanel;
   if (!lvl || batch != 1 || p.ks != 1 || p.pad != 0 || p.stride != 1 || p.up != 0 || p.splitk > 1 || p.rowbias || p.fp8 ||
@@ -2798,6 +3007,13 @@ int af_conv_rowpanel_kind(const ConvGemmParams& p, int batch) {
     if (p.gn_ab && (p.gn_hw <= 0 || p.gn_hw % RowPanelCfg::BM != 0)) return 0;
     if (geglu) return (p.N % RowPanelCfg::BN == 0 && !p.residual && !p.ln_stats_out) ? 1 : 0;
     return (lvl >= 2 && p.N % 160 == 0 && p.alpha == 1.0f && !(p.ln_stats && p.ln_stats_out) && (!p.residual || p.ldr % 4 == 0)) ? 2 : 0;
+  }
+  // few rows, plain epilogue: the 128 x 160 tile GEMM where it puts 128 .. 512 workgroups on the chip and the 256 x 160 tile
+  // would leave a third of it idle (16x16 level: [4096, 1280] -> 1280)
+  if (g_af_knobs.gemm_m128 && !geglu && !p.ln_stats && !p.ln_stats_out && !p.gn_ab && p.M % 128 == 0 && p.M <= 8192 && p.N % 160 == 0 &&
+      p.K % 64 == 0 && p.K >= 256 && (!p.residual || p.ldr % 4 == 0)) {
+    const long nb128 = (long)(p.M / 128) * (p.N / 160), nb256 = (long)((p.M + 255) / 256) * (p.N / 160);
+    if (nb128 >= 128 && nb128 <= 512 && nb256 <= 170) return 6;
   }
   if (p.K == 1280)
     return (lvl >= 4 && p.N == 1280 && p.M >= 4096 && !geglu && p.alpha == 1.0f && !p.ln_stats && !p.ln_stats_out && !p.gn_ab &&
@@ -2860,6 +3076,14 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
     return -1;
   }
   if (p.defer_reduce) g_af_deferred_reduces += 1;
+  if constexpr (sizeof(T) == 2) {
+    // the 128 x 160 tile GEMM fills the chip in one K slice where the 256-row tile was planned over two
+    if (pl.splitk > 1 && !p.defer_reduce) {
+      ConvGemmParams q = p;
+      q.splitk = 1;
+      if (af_conv_rowpanel_kind(q, batch) == 6) pl.splitk = 1;
+    }
+  }
   p.splitk = pl.splitk;
   p.ws = ws;
   g_af_last_plan = pl;
@@ -2915,6 +3139,7 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
       case 3: return launch_plain_rowpanel_k1280(p, stream);
       case 4: return launch_geglu_rowpanel(p, stream, true);
       case 5: return launch_plain_rowpanel(p, stream, true);
+      case 6: return launch_gemm_m128(p, stream);
       default: break;
     }
   }

@@ -42,6 +42,21 @@ def test_library_loads_and_exports_every_symbol():
     assert _lib.load().af_version() >= 1
 
 
+def test_no_wide_store_is_followed_by_a_write_of_its_data_registers():
+    """gfx950 code of every translation unit: no 12/16-byte VMEM store has a data register rewritten by a VALU instruction in
+    the next two slots (hipcc leaves the SGPR-offset form unpadded; seen to store the new value, scripts/check_isa_hazards.py)."""
+    import importlib.util
+    from adaface_amd import _lib, build
+    if not _lib.lib_path().exists() or not list((ROOT / "adaface_amd" / "_build").glob("*.o")):
+        build.build(verbose=False)
+    spec = importlib.util.spec_from_file_location("check_isa_hazards", ROOT / "scripts" / "check_isa_hazards.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    stores, hits = mod.scan(slots=2)
+    assert stores > 500, stores          # (the scan saw the kernels: ~1800 wide stores in the library)
+    assert not hits, hits
+
+
 def test_no_cpu_fallback_in_product():
     """The product package must not import the oracle, and must refuse CPU tensors."""
     for path in (ROOT / "adaface_amd").rglob("*.py"):

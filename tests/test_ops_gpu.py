@@ -254,6 +254,39 @@ def test_conv_gn_producer_refuses_sliced_k(gpu):
         ops.conv_gn(x, w, None, ones, ones * 0)
 
 
+@pytest.mark.parametrize("M,K,N,bias,res", [(4096, 1280, 1280, True, True), (4096, 1280, 1280, False, False), (4096, 5120, 1280, True, True),
+                                            (2048, 1280, 1280, True, False), (8192, 640, 640, True, True), (4096, 256, 1600, True, False)])
+def test_linear_m128_tile(gpu, report, knobs, M, K, N, bias, res):
+    """gemm_m128_kernel (128 x 160 tile, both operands through an LDS-DMA ring): the few-row plain GEMMs of the 16x16 level,
+    against torch and against the kernel it replaces (knob gemm_m128 = 0) on the same operands; 20 repeated launches must be
+    bit-identical (the kernel's first version stored a register the next instruction had rewritten, a few launches in a hundred:
+    scripts/check_isa_hazards.py)."""
+    from adaface_amd import _lib, ops
+    g = torch.Generator().manual_seed(M + K + N)
+    x = _q(torch.randn(M, K, generator=g), "bf16")
+    w = _q(torch.randn(N, K, generator=g) / math.sqrt(K), "bf16")
+    b = torch.randn(N, generator=g) if bias else None
+    r = _q(torch.randn(M, N, generator=g), "bf16") if res else None
+    ref = torch.nn.functional.linear(x, w, b)
+    if res:
+        ref = ref + r
+    args = (x.to(gpu), w.to(gpu), None if b is None else b.to(gpu), None if r is None else r.to(gpu))
+    _lib.plan_counts(reset=True)
+    got = ops.linear(*args, dtype="bf16")
+    pc1 = _lib.plan_counts(reset=True)
+    knobs("gemm_m128", 0)
+    old = ops.linear(*args, dtype="bf16")
+    pc0 = _lib.plan_counts(reset=True)
+    assert pc1["rowpanel"] == 1 and pc1["splitk"] == 0, pc1          # (the m128 launch is counted with the row-panel family)
+    _cmp(report, f"linear m128 [{M},{K}]->{N}", got, ref, "bf16")
+    _cmp(report, f"linear m128 vs previous kernel [{M},{K}]->{N}", got, old, "bf16")
+    again = ops.linear(*args, dtype="bf16")
+    knobs("gemm_m128", 1)
+    assert torch.equal(again, old)
+    for _ in range(20):
+        assert torch.equal(ops.linear(*args, dtype="bf16"), got)
+
+
 @pytest.mark.parametrize("B,C,H,W,N", [(8, 320, 64, 64, 320), (16, 640, 32, 32, 640), (9, 320, 64, 64, 960)])
 def test_groupnorm_in_rowpanel_prologue(gpu, report, knobs, B, C, H, W, N):
     """SpatialTransformer.norm + proj_in with the GroupNorm applied in the row-panel GEMM's prologue (ConvGemmParams::gn_ab):
@@ -315,6 +348,7 @@ def test_plain_rowpanel(gpu, report, knobs, M, K, N, bias, res):
     against torch and, bit for bit, against the tiled eight-wave kernel."""
     from adaface_amd import _lib, ops
     knobs("geglu_rowpanel", 4)
+    knobs("gemm_m128", 0)                  # (the [4096, 1280] -> 1280 shape is the 128 x 160 kernel's by default: test_linear_m128_tile)
     g = torch.Generator().manual_seed(M + N + 5)
     x = _q(torch.randn(M, K, generator=g), "bf16")
     w = _q(torch.randn(N, K, generator=g) / math.sqrt(K), "bf16")
