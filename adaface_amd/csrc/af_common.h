@@ -106,6 +106,11 @@ struct AfKnobs {
                             //                         SLOWER (512 workgroups summing 42 MB of slabs against the reduce kernel's 4096)
   int gn_consumer;          // AF_GN_CONSUMER          0 = the SpatialTransformer's GroupNorm always runs its own apply pass (never
                             //                         in the prologue of a row-panel proj_in)
+  int splitk_inlaunch;      // AF_SPLITK_INLAUNCH      1 = sliced-K launches whose whole grid is resident reduce their slabs themselves
+                            //                         (pp_inlaunch_reduce; bit-identical, 25 fewer launches per forward).  Default 0:
+                            //                         measured 15.72 vs 15.69 ms per forward -- the slabs must go through memory
+                            //                         (the slices of a tile sit on different XCDs), which costs what the launch saved
+  int plan_log;             // AF_PLAN_LOG             1 = one stderr line per GEMM / convolution launch: shape, tile, K slices (lab)
 };
 extern AfKnobs g_af_knobs;
 
@@ -322,6 +327,11 @@ struct ConvGemmParams {
   // split-K launch whose slabs the CONSUMER reduces (a single-launch GroupNorm, af_launch_groupnorm_slabs): no reduce launch,
   // p.out is not written
   int defer_reduce;
+  // split-K launch that reduces its own slabs (set by af_launch_conv_gemm, never by callers): the S workgroups of a tile meet
+  // on sk_sync[2 * tile] and each finishes 1 / S of the tile's rows; no reduce launch.  Only when every workgroup of the grid
+  // is resident at once (grid <= compute units).  sk_sync: zeroed words owned by the library, one set per stream
+  unsigned* sk_sync;
+  int sk_inlaunch;
 };
 
 struct AfGemmPlan {

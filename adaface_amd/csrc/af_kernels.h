@@ -29,6 +29,8 @@ int af_launch_groupnorm_slabs(const float* ws, int splitk, int M, int N, const f
                               int HW, int Cn, const float* gamma, const float* beta, float eps, int silu, void* y, long y_bs,
                               int ldy, hipStream_t stream, float fp8_mul = 0.f);
 extern long g_af_deferred_reduces;
+extern long g_af_inlaunch_reduces;
+long af_sk_timeouts_total();
 // GroupNorm reduced to its per-sample affine map ab_out [B][2][Cn] (scale, shift) for a consumer that applies it itself
 // (ConvGemmParams::gn_ab): statistics pass (unless pre_partial) + fold, no pass that writes the normalised tensor
 template <typename T>

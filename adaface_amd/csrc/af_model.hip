@@ -55,7 +55,8 @@ AfKnobs g_af_knobs = {
     knob_env("AF_LN_FUSE", 1),         knob_env("AF_GEGLU_ROWPANEL", 4), knob_env("AF_CONV_HALO8", 1), knob_env("AF_CONV_FAST_TAPS", 1),
     knob_env("AF_PP_STAGGER", 1),      knob_env("AF_GN_PRODUCER", 1),     knob_env("AF_CONV_UP_PHASE4", 1),
     knob_env("AF_PP_SCHED", 2),        knob_env("AF_ATTN_SHORT", 1),      knob_env("AF_ROWPANEL_DEEP", 1),
-    knob_env("AF_GEMM_M128", 1),       knob_env("AF_SMALL_M_TILE64", 1),  knob_env("AF_GN_REDUCE", 0),       knob_env("AF_GN_CONSUMER", 1)};
+    knob_env("AF_GEMM_M128", 1),       knob_env("AF_SMALL_M_TILE64", 1),  knob_env("AF_GN_REDUCE", 0),       knob_env("AF_GN_CONSUMER", 1),
+    knob_env("AF_SPLITK_INLAUNCH", 0), knob_env("AF_PLAN_LOG", 0)};
 static const AfKnobs g_af_knobs_initial = g_af_knobs;
 static int* knob_slot(const char* name) {
   static const struct { const char* n; int AfKnobs::*m; } tab[] = {
@@ -66,7 +67,7 @@ static int* knob_slot(const char* name) {
       {"gn_small", &AfKnobs::gn_small}, {"gn_fold", &AfKnobs::gn_fold}, {"conv_tap_inner", &AfKnobs::conv_tap_inner}, {"ln_fuse", &AfKnobs::ln_fuse},
       {"geglu_rowpanel", &AfKnobs::geglu_rowpanel}, {"conv_halo8", &AfKnobs::conv_halo8}, {"conv_fast_taps", &AfKnobs::conv_fast_taps}, {"pp_stagger", &AfKnobs::pp_stagger}, {"gn_producer", &AfKnobs::gn_producer}, {"conv_up_phase4", &AfKnobs::conv_up_phase4}, {"pp_sched", &AfKnobs::pp_sched},
       {"attn_short", &AfKnobs::attn_short}, {"rowpanel_deep", &AfKnobs::rowpanel_deep},
-      {"gemm_m128", &AfKnobs::gemm_m128}, {"small_m_tile64", &AfKnobs::small_m_tile64}, {"gn_reduce", &AfKnobs::gn_reduce}, {"gn_consumer", &AfKnobs::gn_consumer}};
+      {"gemm_m128", &AfKnobs::gemm_m128}, {"small_m_tile64", &AfKnobs::small_m_tile64}, {"gn_reduce", &AfKnobs::gn_reduce}, {"gn_consumer", &AfKnobs::gn_consumer}, {"splitk_inlaunch", &AfKnobs::splitk_inlaunch}, {"plan_log", &AfKnobs::plan_log}};
   if (!name) return nullptr;
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) return &(g_af_knobs.*(t.m));
@@ -2298,6 +2299,7 @@ int af_gemm_plan_counts_reset(void) {
   g_af_attn_short_launches = 0;
   g_af_gn_consumer_launches = 0;
   g_af_deferred_reduces = 0;
+  g_af_inlaunch_reduces = 0;
   for (int i = 0; i < 15; ++i) g_af_plan_counts[i] = 0;
   return AF_OK;
 }
@@ -2309,6 +2311,8 @@ int64_t af_gn_producer_launches(void) { return g_af_plan_counts[14]; }
 int64_t af_attn_short_launches(void) { return g_af_attn_short_launches; }
 int64_t af_gn_consumer_launches(void) { return g_af_gn_consumer_launches; }
 int64_t af_deferred_reduces(void) { return g_af_deferred_reduces; }
+int64_t af_inlaunch_reduces(void) { return g_af_inlaunch_reduces; }
+int64_t af_inlaunch_reduce_timeouts(void) { return af_sk_timeouts_total(); }
 int af_set_fp8(af_handle* h, int on) {
   if (!h) { af_set_error_msg("af_set_fp8: null handle"); return AF_ERR_INVALID; }
   if (on && h->dtype != AF_DTYPE_BF16) { af_set_error_msg("af_set_fp8: the fp8 convolutions extend the bf16 mode (handle is f32)"); return AF_ERR_STATE; }

@@ -246,6 +246,12 @@ int64_t af_attn_short_launches(void);
 int64_t af_gn_consumer_launches(void);
 /* sliced-K convolutions whose fp32 slabs were reduced by the single-launch GroupNorm that consumes them (no reduce launch) */
 int64_t af_deferred_reduces(void);
+/* sliced-K launches that reduced their fp32 slabs themselves (the slices of a tile meet on a counter and each finishes a share
+ * of its rows; only when the whole grid is resident at once) -- no splitk_reduce launch */
+int64_t af_inlaunch_reduces(void);
+/* waits of that reduction that gave up (a slice never arrived within ~0.5 s; the launch's outputs are then wrong), summed over
+ * the process's streams.  Synchronises the device.  0 in every test, smoke() and bench.py run. */
+int64_t af_inlaunch_reduce_timeouts(void);
 int64_t af_up_phase4_launches(void); /* upsampled 3x3 convolutions run as four 2x2 phase convolutions on the stored map */
 int64_t af_rowpanel_launches(void); /* launches of the row-panel kernels (K = 320 / 640 / 1280 GEMMs with the activation rows resident in registers) */
 int af_op_conv2d_fp8(const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev, float* y_dev,
