@@ -377,12 +377,14 @@ def test_sd15_unet_new_fused_paths_ab(gpu, report, knobs):
         _assert_bf16_ab(report, f"sd15_unet Bf=16 with (A) / without (B) {knob}", full, out, ref)
 
 
-@pytest.mark.parametrize("B,H,W", [(16, 48, 48), (6, 96, 64), (3, 40, 24)])
+@pytest.mark.parametrize("B,H,W", [(16, 48, 48), (6, 96, 64), (3, 40, 24), (6, 64, 64), (10, 64, 64), (14, 64, 64)])
 def test_sd15_unet_other_latent_sizes(gpu, report, B, H, W):
     """Latent sizes other than the benchmark's 64 x 64 (the planner's fall-backs: 48 x 48 -> 2304 pixels per sample, row-panel
     launches and the GroupNorm-in-prologue path but no LDS-halo convolution (Wo = 48); 96 x 64 -> halo rows of a non
     power-of-two image height; 40 x 24 with an odd batch -> below every row-panel threshold, ragged query blocks in the
-    short-key attention): the bf16 forward against the f32-mode forward of the same batch, per-forward bars."""
+    short-key attention) and 64 x 64 with CFG batches of 3 / 5 / 7 images (384 / 640 / 896 rows on the 8 x 8 map: ragged row
+    tiles of the sliced-K launches, 1536 / 2560 / 3584 rows at 16 x 16: the 128 x 160 GEMM off and on its row limits): the bf16
+    forward against the f32-mode forward of the same batch, per-forward bars."""
     from adaface_amd.engine import Engine
     from adaface_amd.synth import synth_weights_into
     cfg = O.SD15_UNET
