@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event roofline leg")
     ap.add_argument("--no-parity-leg", action="store_true",
                     help="skip the untimed f32-mode batch (f32-mode images/s and the bf16 final-latent deviation)")
+    ap.add_argument("--no-inflight-leg", action="store_true",
+                    help="skip the untimed-for-`value` serving leg (two independent batch-8 requests in flight on two HIP streams)")
     ap.add_argument("--event-stride", type=int, default=7,
                     help="HIP-event bracket every n-th GEMM / attention launch inside the timed region (1 = all)")
     ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)
@@ -193,15 +195,19 @@ def main():
         from adaface_amd import _lib
         from ldm.models.diffusion.ddim import DDIMSampler
         lib = _lib.load()
-        model = build_model(device, args.dtype)
-        sampler = DDIMSampler(model)
-        uc = model.get_learned_conditioning(uc_emb)
-        conds = [model.get_learned_conditioning(c_all[i * B * 16:(i + 1) * B * 16]) for i in range(n_micro)]
+        def make_runner(mdl):
+            smp = DDIMSampler(mdl)
+            uc_ = mdl.get_learned_conditioning(uc_emb)
+            conds_ = [mdl.get_learned_conditioning(c_all[i * B * 16:(i + 1) * B * 16]) for i in range(n_micro)]
 
-        def run_micro(x_T, cond):
-            samples, _ = sampler.sample(S=S, conditioning=cond, batch_size=B, shape=[4, 64, 64], verbose=False,
-                                        guidance_scale=[10.0, 4.0], unconditional_conditioning=uc, eta=0.0, x_T=x_T)
-            return model.decode_first_stage_uint8(samples), samples
+            def run(x_T, cond):
+                samples, _ = smp.sample(S=S, conditioning=cond, batch_size=B, shape=[4, 64, 64], verbose=False,
+                                        guidance_scale=[10.0, 4.0], unconditional_conditioning=uc_, eta=0.0, x_T=x_T)
+                return mdl.decode_first_stage_uint8(samples), samples
+            return run, conds_
+
+        model = build_model(device, args.dtype)
+        run_micro, conds = make_runner(model)
 
     last_latent = [None]
 
@@ -304,6 +310,51 @@ def main():
                     "conv_linear_class": {"kernels": [K_NAMES[c] for c in GEMM_CLASSES], "achieved": cls_fl / (cls_ms * 1e-3) / 1e12,
                                           "frac": cls_fl / (cls_ms * 1e-3) / peak, "launches_timed": int(cls_n)}}
 
+    # ---- serving leg (rank 0, N = 1; NOT `value`): two independent batch-B requests in flight on two HIP streams ----
+    # Between two dependent launches of ONE request the device idles for a couple of microseconds (drain, dispatch, ramp: ~460
+    # launches per UNet forward); a second request's launches fill those gaps.  Two engines (each its own weights, arena and
+    # stream), two host threads.  Reported beside the headline, never in it: the headline is one batch of 8 at a time.
+    inflight = None
+    if rank == 0 and world == 1 and not stub and not args.no_inflight_leg and n_micro == 1:
+        try:
+            import threading
+            model_b = build_model(device, args.dtype)
+            run_b, conds_b = make_runner(model_b)
+            lanes = [(run_micro, conds[0], torch.cuda.Stream()), (run_b, conds_b[0], torch.cuda.Stream())]
+            n_each = max(1, min(args.steps, 2))
+            errs = []
+
+            def lane(run, cond, stream, n):
+                try:
+                    torch.cuda.set_device(device)
+                    with torch.cuda.stream(stream):
+                        for _ in range(n):
+                            run(x_T_all[:B], cond)
+                except Exception as e:  # noqa: BLE001  (reported in the JSON line; the headline is already measured)
+                    errs.append(repr(e))
+
+            def both(n):
+                th = [threading.Thread(target=lane, args=(r, c, st, n)) for r, c, st in lanes]
+                for t_ in th:
+                    t_.start()
+                for t_ in th:
+                    t_.join()
+                torch.cuda.synchronize()
+
+            torch.cuda.synchronize()
+            both(1)                                   # warm-up: second engine's first call, both streams' first launches
+            ta = time.perf_counter()
+            both(n_each)
+            tb = time.perf_counter() - ta
+            inflight = {"value": 2 * n_each * B / tb, "unit": "images/sec", "requests_in_flight": 2, "batch_per_request": B,
+                        "batches_timed": 2 * n_each, "ms_per_pair_of_batches": 1e3 * tb / n_each, "errors": errs or None,
+                        "note": "two independent batch-%d requests (two engines, two HIP streams, two host threads); NOT the headline "
+                                "`value`, which runs one batch at a time" % B}
+            del model_b, run_b, conds_b, lanes
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            inflight = {"value": None, "errors": [repr(e)]}
+
     # ---- untimed parity leg (rank 0, N = 1): the SAME batch in f32 parity mode ----
     parity = None
     if rank == 0 and world == 1 and not stub and not args.no_parity_leg and args.dtype in ("bf16", "fp8"):
@@ -350,7 +401,7 @@ def main():
             "executed_over_reference_flops": (flops_executed / (images / world * flop_img) if flops_executed else None),
             "device_clock_probe": clock,
             "distributed": dict(STATS),
-            "roofline": roof, "kernels": kernels, "parity": parity,
+            "roofline": roof, "kernels": kernels, "parity": parity, "two_requests_in_flight": inflight,
         }
         if stub:
             res.update(metric="PLUMBING TEST - stub in place of the HIP path, nothing measured", value=None, dtype="none",
