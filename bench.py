@@ -69,6 +69,10 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event roofline leg")
     ap.add_argument("--no-parity-leg", action="store_true",
                     help="skip the untimed f32-mode batch (f32-mode images/s and the bf16 final-latent deviation)")
+    ap.add_argument("--pipeline-decode", action="store_true",
+                    help="AutoencoderKL.decode + the frame all-gather of batch i on a second HIP stream under the denoising of batch "
+                         "i + 1 (same work, same batches; measured +0.4 %%: the decoder's kernels fill the chip themselves, so only "
+                         "launch gaps are shared).  Default: everything on the sampling stream")
     ap.add_argument("--no-inflight-leg", action="store_true",
                     help="skip the untimed-for-`value` serving leg (two independent batch-8 requests in flight on two HIP streams)")
     ap.add_argument("--event-stride", type=int, default=7,
@@ -200,10 +204,15 @@ def main():
             uc_ = mdl.get_learned_conditioning(uc_emb)
             conds_ = [mdl.get_learned_conditioning(c_all[i * B * 16:(i + 1) * B * 16]) for i in range(n_micro)]
 
-            def run(x_T, cond):
+            def denoise(x_T, cond):
                 samples, _ = smp.sample(S=S, conditioning=cond, batch_size=B, shape=[4, 64, 64], verbose=False,
                                         guidance_scale=[10.0, 4.0], unconditional_conditioning=uc_, eta=0.0, x_T=x_T)
+                return samples
+
+            def run(x_T, cond):
+                samples = denoise(x_T, cond)
                 return mdl.decode_first_stage_uint8(samples), samples
+            run.denoise, run.decode = denoise, mdl.decode_first_stage_uint8
             return run, conds_
 
         model = build_model(device, args.dtype)
@@ -211,12 +220,31 @@ def main():
 
     last_latent = [None]
 
+    # Decode pipeline: the UNet (its own engine, arena and the sampling stream) and the VAE decoder (its own engine, always on
+    # `side`) are independent once a batch's latents exist, so batch i is decoded -- and its frames gathered -- under the
+    # denoising of batch i + 1.  Every step still denoises and decodes one whole batch; fence() waits for both streams.
+    pipe = not stub and args.pipeline_decode
+    side = torch.cuda.Stream(device) if pipe else None
+
     def step():
         frames = []
         for i in range(n_micro):
-            f, lat = run_micro(x_T_all[i * B:(i + 1) * B], c_all[i * B * 16:(i + 1) * B * 16] if stub else conds[i])
+            if pipe:
+                lat = run_micro.denoise(x_T_all[i * B:(i + 1) * B], conds[i])
+                ready = torch.cuda.Event()
+                ready.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    f = run_micro.decode(lat)
+                lat.record_stream(side)
+            else:
+                f, lat = run_micro(x_T_all[i * B:(i + 1) * B], c_all[i * B * 16:(i + 1) * B * 16] if stub else conds[i])
             frames.append(f)
             last_latent[0] = lat
+        if pipe:
+            with torch.cuda.stream(side):
+                frames = frames[0] if n_micro == 1 else torch.cat(frames)
+                return gather_frames(frames, global_batch=G)  # one RCCL all-gather per step (no-op at N=1), behind the decodes
         frames = frames[0] if n_micro == 1 else torch.cat(frames)
         return gather_frames(frames, global_batch=G)  # one RCCL all-gather per step (no-op at N=1)
 
@@ -389,7 +417,9 @@ def main():
                                    + (" with per-layer AdaPrompt subject rows 6..21" if args.workload == "config2" else "")
                                    + (" with a synthetic unit-norm 512-d identity embedding (zero-padded to 768) in rows 4..19 of "
                                       "every layer copy; ResBlock 3x3 convolutions with e4m3 operands" if args.workload == "config4" else "")
-                                   + ", random-init weights",
+                                   + ", random-init weights"
+                                   + ("; AutoencoderKL.decode + frame gather of batch i on a second HIP stream under the denoising "
+                                      "of batch i+1" if pipe else "; decode on the sampling stream"),
                        "global_batch": G, "latent": [4, 64, 64], "guidance_scale": [10.0, 4.0], "parallelism": f"dp{world}"},
             "whole_path_algorithmic_tflops": value * flop_img / 1e12 / world,
             "whole_path_frac_of_mfma_peak": value * flop_img / world / (PEAK_F32 if args.dtype == "f32" else PEAK_BF16),
@@ -402,6 +432,7 @@ def main():
             "device_clock_probe": clock,
             "distributed": dict(STATS),
             "roofline": roof, "kernels": kernels, "parity": parity, "two_requests_in_flight": inflight,
+            "decode_pipelined": bool(pipe),
         }
         if stub:
             res.update(metric="PLUMBING TEST - stub in place of the HIP path, nothing measured", value=None, dtype="none",
