@@ -10,9 +10,9 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${AF_TAG:-rXX}; SHA=${AF_COMMIT:-nocommit}
 for mode in bf16 fp8; do
   D=gpurun_out/prof_$mode; rm -rf $D; mkdir -p $D
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python bench.py --dtype $mode --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --no-parity-leg > $D/out.txt 2>&1 || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python bench.py --dtype $mode --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --no-parity-leg --no-inflight-leg > $D/out.txt 2>&1 || exit 1
   T=$(find $D -name "*kernel_trace.csv" | head -1); S=$(find $D -name "*kernel_stats.csv" | head -1)
-  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --dtype $mode --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --no-parity-leg   (commit $SHA)"; tail -1 $D/out.txt | cut -c1-400; python scripts/summarize_trace.py $T; } > gpurun_out/${TAG}_summary_${mode}_${SHA}.txt
+  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --dtype $mode --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --no-parity-leg --no-inflight-leg   (commit $SHA)"; tail -1 $D/out.txt | cut -c1-400; python scripts/summarize_trace.py $T; } > gpurun_out/${TAG}_summary_${mode}_${SHA}.txt
   cp $S gpurun_out/${TAG}_kernel_stats_${mode}_${SHA}.csv
   find $D -name "*.csv" -size +1M -delete
 done

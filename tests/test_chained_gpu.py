@@ -79,7 +79,7 @@ def test_bench_under_torchrun_world1_runs_rccl(gpu):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
            "--master-port", "29731", os.fspath(ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
-           "--no-cpu-baseline", "--no-parity-leg", "--no-kernel-timing"]
+           "--no-cpu-baseline", "--no-parity-leg", "--no-kernel-timing", "--no-inflight-leg"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
