@@ -2105,15 +2105,21 @@ static int launch_plain_rowpanel(const ConvGemmParams& p, hipStream_t stream, bo
 }
 
 // ---------------------------------------------------------------------------
-// 128 x 160 tile GEMM for FEW rows (round 3): the plain 1x1 GEMMs of the 16x16 level, [4096, 1280] -> 1280 (25 per forward).
+// 128 x 160 tile GEMM for FEW rows (round 3): the plain 1x1 GEMMs of the 16x16 level, [4096, 1280] -> 1280 and
+// [4096, 5120] -> 1280 (36 per forward).
 //
-// 4096 rows are sixteen 256-row tiles: the 256 x 160 ping-pong tile leaves half of the chip idle (128 workgroups, 30 us) and
-// the K = 1280 row-panel form fills it only by having eight workgroups re-load each 128-row panel into registers (320 KB per
-// workgroup in fragment-shaped 16-byte loads: its texture-address FIFO is full 13-16 % of the time, 28 us).  Here a workgroup
-// owns 128 rows x 160 columns (32 x 8 = 256 workgroups), BOTH operands stream through a four-slot LDS ring in whole 128-byte
-// lines by LDS-DMA (16 + 20 pieces of 1 KiB per K step, 4-5 per wave), prefetch distance three steps, one barrier per step;
-// eight waves as 2 column halves x 4 row quarters, 32 rows x 80 columns each (2 x 5 MFMA 16x16x32 blocks, 20 MFMAs per
-// step).  Swizzle, fragment addressing and the transposed epilogue are those of rowpanel_kernel.
+// 4096 rows are sixteen 256-row tiles: the 256 x 160 ping-pong tile leaves half of the chip idle (128 workgroups, 30 us; or two
+// K slices and a reduce launch) and the K = 1280 row-panel form fills it only by having eight workgroups re-load each 128-row
+// panel into registers (320 KB per workgroup in fragment-shaped 16-byte loads: its texture-address FIFO is full 13-16 % of the
+// time, 28 us).  Here a workgroup owns 128 rows x 160 columns (32 x 8 = 256 workgroups, ONE K slice), BOTH operands stream
+// through an LDS ring of D + 1 slots in whole 128-byte lines by LDS-DMA (16 + 20 pieces of 1 KiB per K step, 4-5 per wave),
+// prefetch distance D = 2 steps (3 measured the same), one barrier per step; eight waves as 2 column halves x 4 row quarters,
+// 32 rows x 80 columns each (2 x 5 MFMA 16x16x32 blocks, 20 MFMAs per step).  Swizzle, fragment addressing and the transposed
+// epilogue are those of rowpanel_kernel.  21.5 us ([4096, 1280] -> 1280), 60.8 us (K = 5120).
+//
+// The epilogue's 16-byte stores: all chunks and offsets first, then the stores back to back (see the comment there and
+// scripts/check_isa_hazards.py) -- the first version let hipcc put the next chunk's address arithmetic between them and stored
+// rewritten registers.
 // ---------------------------------------------------------------------------
 template <int D_> struct M128CfgT {
   static constexpr int BM = 128, BN = 160, D = D_, NS = D + 1;
@@ -3134,7 +3140,7 @@ int af_conv_rowpanel_kind(const ConvGemmParams& p, int batch) {
   // few rows, plain epilogue: the 128 x 160 tile GEMM where it puts 128 .. 512 workgroups on the chip and the 256 x 160 tile
   // would leave a third of it idle (16x16 level: [4096, 1280] -> 1280)
   if (g_af_knobs.gemm_m128 && !geglu && !p.ln_stats && !p.ln_stats_out && !p.gn_ab && p.M % 128 == 0 && p.M <= 8192 && p.N % 160 == 0 &&
-      p.K % 64 == 0 && p.K >= 256 && (!p.residual || p.ldr % 4 == 0)) {
+      p.K % 64 == 0 && p.K >= 256 && (!p.residual || p.ldr % 4 == 0) && p.ldo % 8 == 0 && ((__UINTPTR_TYPE__)p.out & 15) == 0) {
     const long nb128 = (long)(p.M / 128) * (p.N / 160), nb256 = (long)((p.M + 255) / 256) * (p.N / 160);
     if (nb128 >= 128 && nb128 <= 512 && nb256 <= 170) return 6;
   }
