@@ -3143,6 +3143,9 @@ int af_conv_rowpanel_kind(const ConvGemmParams& p, int batch) {
       p.K % 64 == 0 && p.K >= 256 && (!p.residual || p.ldr % 4 == 0) && p.ldo % 8 == 0 && ((__UINTPTR_TYPE__)p.out & 15) == 0) {
     const long nb128 = (long)(p.M / 128) * (p.N / 160), nb256 = (long)((p.M + 255) / 256) * (p.N / 160);
     if (nb128 >= 128 && nb128 <= 512 && nb256 <= 170) return 6;
+    // ... and where 128-row tiles come out as whole rounds of 256 workgroups while 256-row tiles do not ([4096, 1280] -> 3840:
+    // 768 against 384 = one and a half rounds; 59 -> 52 us)
+    if (nb128 % 256 == 0 && nb128 <= 1024 && nb256 % 256 != 0) return 6;
   }
   if (p.K == 1280)
     return (lvl >= 4 && p.N == 1280 && p.M >= 4096 && !geglu && p.alpha == 1.0f && !p.ln_stats && !p.ln_stats_out && !p.gn_ab &&
