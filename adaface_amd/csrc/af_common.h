@@ -85,7 +85,8 @@ struct AfKnobs {
   int gn_small;             // AF_GN_SMALL             0 = no single-launch GroupNorm for small maps
   int gn_fold;              // AF_GN_FOLD              0 = separate GroupNorm finalize pass
   int conv_tap_inner;       // AF_CONV_TAP_INNER       0 = ping-pong convs walk K tap-outermost (the round-1 order)
-  int ln_fuse;              // AF_LN_FUSE              0 = stand-alone LayerNorm kernels in front of the transformer GEMMs
+  int ln_fuse;              // AF_LN_FUSE              0 = stand-alone LayerNorm kernels in front of the transformer GEMMs; 3 = folded at
+                            //                         the 16x16 level as well (128 x 160 tile GEMM epilogues; measured neutral)
   int geglu_rowpanel;       // AF_GEGLU_ROWPANEL       row-panel kernel (K = 320, >= 32768 rows): 0 = never, 1 = GEGLU only, 2 = the plain
                             //                         GEMMs of the 64x64-level transformers too, 3 = and its K = 640 form (GEGLU and
                             //                         q / k / v of the 32x32 level, >= 16384 rows), 4 = and the K = 1280 form

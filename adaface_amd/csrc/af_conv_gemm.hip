@@ -2135,7 +2135,11 @@ template <int D_> struct M128CfgT {
   static_assert(LDS_BYTES <= 160 * 1024 && 8 * OBYTES <= NS * SLOT && (32 * CPR) % 64 == 0, "m128 LDS / store mapping");
 };
 
-template <bool RES, int DEPTH>
+// LNMODE as in conv_gemm_pp_kernel / rowpanel_kernel: 1 = LayerNorm consumer (rows un-normalised, W * gamma; the epilogue
+// applies rstd * (acc - mu * colsum) + bias; (mu, rstd) from ln_stats or, ln_parts_n > 0, summed here from the producer's
+// partial sums like ln_finalize_kernel does), 2 = statistics producer (per-row (sum, sum of squares) of the bf16 values stored,
+// slab tn * 2 + g of [N / 80][M][2] -- the tiled kernel's layout)
+template <bool RES, int DEPTH, int LNMODE>
 __global__ __launch_bounds__(512) void gemm_m128_kernel(const ConvGemmParams p) {
   using C = M128CfgT<DEPTH>;
   typedef bf16 T;
@@ -2239,9 +2243,61 @@ __global__ __launch_bounds__(512) void gemm_m128_kernel(const ConvGemmParams p) 
     pp_wait_lgkm0();
   };
 
+  // LayerNorm consumer: (mu, rstd) of this lane's two rows, fetched BEFORE the first LDS-DMA is issued (the loop's vmcnt
+  // arithmetic counts DMA pieces only; hipcc's own waits for these loads then leave the pieces in flight)
+  float ln_mu[LNMODE == 1 ? MJ : 1], ln_rs[LNMODE == 1 ? MJ : 1];
+  constexpr int LNP = 16;                       // partial-sum slabs fetched at once (N = 1280: 16; more: the loop below)
+  float2 ln_part[LNMODE == 1 ? MJ : 1][LNMODE == 1 ? LNP : 1];
+  if constexpr (LNMODE == 1) {
+    // every slab of both rows in flight at once (out-of-range offsets = zeros, no branches): summed one after the other in a
+    // loop these 8-byte loads cost 16 memory latencies per launch
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ln_stats), 0, (int)0xFFFFFFF8u, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+      const int m = m0 + wq * 32 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int q = 0; q < LNP; ++q) {
+        const bool live = m < p.M && (p.ln_parts_n > 0 ? q < p.ln_parts_n : q == 0);
+        const unsigned off = live ? (unsigned)(((long)q * p.M + m) * 8) : 0xFFFFFFFFu;
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs_s, off, 0, 0);
+        ln_part[j][q] = float2{__uint_as_float(v.x), __uint_as_float(v.y)};
+      }
+    }
+  }
+  auto ln_finish = [&]() {
+    if constexpr (LNMODE == 1) {
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) {
+        const int m = m0 + wq * 32 + j * 16 + (lane & 15);
+        if (p.ln_parts_n > 0) {                 // same order and arithmetic as ln_finalize_kernel
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int q = 0; q < LNP; ++q)
+            if (q < p.ln_parts_n) { s1 += ln_part[j][q].x; s2 += ln_part[j][q].y; }
+          for (int q = LNP; q < p.ln_parts_n; ++q) {
+            const float2 pq2 = m < p.M ? *reinterpret_cast<const float2*>(p.ln_stats + ((long)q * p.M + m) * 2) : float2{0.f, 0.f};
+            s1 += pq2.x;
+            s2 += pq2.y;
+          }
+          const float mu = s1 * p.ln_inv_count;
+          const float var = fmaxf(s2 * p.ln_inv_count - mu * mu, 0.f);
+          ln_mu[j] = mu;
+          ln_rs[j] = __builtin_amdgcn_rsqf(var + p.ln_eps);
+        } else {
+          ln_mu[j] = ln_part[j][0].x;
+          ln_rs[j] = ln_part[j][0].y;
+        }
+      }
+      // (all of them consumed before the loop: its vmcnt arithmetic counts LDS-DMA pieces only)
+      asm volatile("s_nop 0" : "+v"(ln_mu[0]), "+v"(ln_rs[0]), "+v"(ln_mu[MJ - 1]), "+v"(ln_rs[MJ - 1])::"memory");
+    }
+  };
+
   // ---- main loop: step t in slot t % NS; steps 0 .. D-1 in flight ----
 #pragma unroll
   for (int i = 0; i < D; ++i) stage(i, i);
+  ln_finish();                                  // (the statistics loads were issued before the pieces: older, so already waited for)
   int cur = 0;
   for (int t = 0; t < KT; ++t) {
     // own pieces of step t landed: everything but the pieces of the next D - 1 steps (2 + nwq per step); in the last D - 1
@@ -2260,10 +2316,12 @@ __global__ __launch_bounds__(512) void gemm_m128_kernel(const ConvGemmParams p) 
   // ---- epilogue: bias (+ residual) in the accumulator layout, bf16 through the wave-private tile, 16-byte row stores ----
   char* otile = smem + C::OTILE0 + wid * C::OBYTES;
   const int r0 = m0 + wq * 32, ncol = n0 + g * 80;
-  float4 bvec[NI];
+  float4 bvec[NI], cvec[LNMODE == 1 ? NI : 1];
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
+  for (int i = 0; i < NI; ++i) {
     bvec[i] = p.bias ? *reinterpret_cast<const float4*>(p.bias + ncol + i * 16 + cl) : float4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (LNMODE == 1) cvec[i] = *reinterpret_cast<const float4*>(p.ln_colsum + ncol + i * 16 + cl);
+  }
 #pragma unroll
   for (int j = 0; j < MJ; ++j) {
     const int m = r0 + j * 16 + (lane & 15);
@@ -2274,17 +2332,32 @@ __global__ __launch_bounds__(512) void gemm_m128_kernel(const ConvGemmParams p) 
 #pragma unroll
       for (int i = 0; i < NI; ++i) rq[i].load(rp + i * 16);
     }
+    float ps = 0.f, pq = 0.f;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const float* bp = reinterpret_cast<const float*>(&bvec[i]);
+      const float* cp = reinterpret_cast<const float*>(&cvec[LNMODE == 1 ? i : 0]);
       Quad<T> o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float v = acc[i][j][e] * p.alpha + bp[e];
+        float v;
+        if constexpr (LNMODE == 1) v = (acc[i][j][e] - ln_mu[j] * cp[e]) * ln_rs[j] + bp[e];
+        else v = acc[i][j][e] * p.alpha + bp[e];
         if constexpr (RES) v += to_f32<T>(rq[i].e[e]);
         o.e[e] = from_f32<T>(v);
+        if constexpr (LNMODE == 2) {
+          const float vr = mok ? to_f32<T>(o.e[e]) : 0.f;     // the value the consumer will read
+          ps += vr;
+          pq += vr * vr;
+        }
       }
       o.store(reinterpret_cast<T*>(otile + (j * 16 + (lane & 15)) * C::OPITCH) + i * 16 + cl);
+    }
+    if constexpr (LNMODE == 2) {
+      ps += __shfl_xor(ps, 16, 64); pq += __shfl_xor(pq, 16, 64);
+      ps += __shfl_xor(ps, 32, 64); pq += __shfl_xor(pq, 32, 64);
+      if (mok && (lane >> 4) == 0)
+        *reinterpret_cast<float2*>(p.ln_stats_out + ((long)(tn * 2 + g) * p.M + m) * 2) = float2{ps, pq};
     }
   }
   // All chunks and offsets first, then the stores back to back with nothing between them: a 16-byte buffer store whose data
@@ -2305,17 +2378,19 @@ __global__ __launch_bounds__(512) void gemm_m128_kernel(const ConvGemmParams p) 
   for (int i = 0; i < NST; ++i) __builtin_amdgcn_raw_buffer_store_b128(ov[i], rs_o, ooff[i], ncol * 2, 0);
 }
 
-template <bool RES, int DEPTH> static int launch_gemm_m128_one(const ConvGemmParams& p, hipStream_t stream) {
+template <bool RES, int DEPTH, int LNMODE> static int launch_gemm_m128_one(const ConvGemmParams& p, hipStream_t stream) {
   using C = M128CfgT<DEPTH>;
   static unsigned long long attr_done = 0;
-  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&gemm_m128_kernel<RES, DEPTH>), C::LDS_BYTES)) return rc;
+  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&gemm_m128_kernel<RES, DEPTH, LNMODE>), C::LDS_BYTES)) return rc;
   dim3 grid((p.M / C::BM) * (p.N / C::BN), 1, 1);
-  hipLaunchKernelGGL((gemm_m128_kernel<RES, DEPTH>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_m128_kernel<RES, DEPTH, LNMODE>), grid, dim3(512), C::LDS_BYTES, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 static int launch_gemm_m128(const ConvGemmParams& p, hipStream_t stream) {
-  return p.residual ? launch_gemm_m128_one<true, 2>(p, stream) : launch_gemm_m128_one<false, 2>(p, stream);
+  if (p.ln_stats) return p.residual ? launch_gemm_m128_one<true, 2, 1>(p, stream) : launch_gemm_m128_one<false, 2, 1>(p, stream);
+  if (p.ln_stats_out) return p.residual ? launch_gemm_m128_one<true, 2, 2>(p, stream) : launch_gemm_m128_one<false, 2, 2>(p, stream);
+  return p.residual ? launch_gemm_m128_one<true, 2, 0>(p, stream) : launch_gemm_m128_one<false, 2, 0>(p, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -3139,7 +3214,8 @@ int af_conv_rowpanel_kind(const ConvGemmParams& p, int batch) {
   }
   // few rows, plain epilogue: the 128 x 160 tile GEMM where it puts 128 .. 512 workgroups on the chip and the 256 x 160 tile
   // would leave a third of it idle (16x16 level: [4096, 1280] -> 1280)
-  if (g_af_knobs.gemm_m128 && !geglu && !p.ln_stats && !p.ln_stats_out && !p.gn_ab && p.M % 128 == 0 && p.M <= 8192 && p.N % 160 == 0 &&
+  if (g_af_knobs.gemm_m128 && !geglu && !(p.ln_stats && p.ln_stats_out) && (!p.ln_stats || p.alpha == 1.0f) && !p.gn_ab && p.M % 128 == 0 &&
+      p.M <= 8192 && p.N % 160 == 0 &&
       p.K % 64 == 0 && p.K >= 256 && (!p.residual || p.ldr % 4 == 0) && p.ldo % 8 == 0 && ((__UINTPTR_TYPE__)p.out & 15) == 0) {
     const long nb128 = (long)(p.M / 128) * (p.N / 160), nb256 = (long)((p.M + 255) / 256) * (p.N / 160);
     if (nb128 >= 128 && nb128 <= 512 && nb256 <= 170) return 6;
@@ -3272,13 +3348,15 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   AfProfScope prof(prof_cls, stream, 2.0 * p.M * (double)p.N * (p.k_logical ? p.k_logical : p.K) * batch,
                    ((double)p.M * p.K / (p.ks * p.ks) + (double)p.N * p.K + (double)p.M * p.N) * batch * sizeof(T));
   int rc;
-  if ((p.ln_stats || p.ln_stats_out) && !(pl.tile >= 4 && !pl.halo_tw)) {
+  int rk_pre = 0;
+  if constexpr (sizeof(T) == 2) rk_pre = af_conv_rowpanel_kind(p, batch);
+  if ((p.ln_stats || p.ln_stats_out) && rk_pre != 6 && !(pl.tile >= 4 && !pl.halo_tw)) {   // (the 128 x 160 GEMM has both epilogues whatever was planned)
     af_set_error_msg("conv_gemm: LayerNorm-fused launch planned on a kernel without that epilogue (tile %d)", pl.tile);
     return -1;
   }
   // the row-panel kernels (activation rows resident in registers): K = 320 / 640 / 1280 GEMMs with enough rows
   if constexpr (sizeof(T) == 2) {
-    const int rk = af_conv_rowpanel_kind(p, batch);
+    const int rk = rk_pre;
     if (p.ln_parts_n > 0 && !rk) {
       af_set_error_msg("conv_gemm: un-finalised LayerNorm statistics handed to a launch that is not a row-panel one");
       return -1;

@@ -854,6 +854,13 @@ struct Runner {
     ConvGemmParams p;
     conv_params(p, L, x, out, 1, 0, nullptr, nullptr, 0, n_valid, -1);
     const AfGemmPlan pl = af_plan_conv_gemm(p, 1, (int)esize(dt));
+    {   // the 128 x 160 tile GEMM (16x16 level) carries both epilogues, in the tiled kernel's slab layout (80 columns per slab)
+      ConvGemmParams q = p;
+      q.splitk = 1;
+      // (ln_fuse = 3 only: at the 16x16 level the fold measures neutral, 15.834 vs 15.842 ms per forward -- a stand-alone
+      // LayerNorm over [4096, 1280] costs what the two epilogues and the statistics traffic cost)
+      if (g_af_knobs.ln_fuse == 3 && af_conv_rowpanel_kind(q, 1) == 6) return (p.N / 160) * 2;
+    }
     if (pl.tile < 4 || pl.splitk > 1 || pl.halo_tw) return 0;
     return (p.N / (pl.tile == 5 ? 160 : 128)) * 2;
   }
@@ -912,7 +919,12 @@ struct Runner {
     if (ln_parts_pending) {
       ConvGemmParams q = p;
       q.splitk = pl.splitk;
-      if (dt == AF_DTYPE_BF16 && af_conv_rowpanel_kind(q, 1)) {
+      int kind = dt == AF_DTYPE_BF16 ? af_conv_rowpanel_kind(q, 1) : 0;
+      if (!kind && dt == AF_DTYPE_BF16 && pl.splitk > 1) {   // (the launcher drops the K slices of a plan the 128 x 160 GEMM takes)
+        q.splitk = 1;
+        if (af_conv_rowpanel_kind(q, 1) == 6) kind = 6;
+      }
+      if (kind) {
         p.ln_stats = ln->parts_in;
         p.ln_parts_n = ln->parts_n;
         p.ln_inv_count = 1.0f / (float)ln->count;
