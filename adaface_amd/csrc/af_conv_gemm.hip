@@ -2129,7 +2129,7 @@ template <int D_> struct M128CfgT {
   static constexpr int OCOLS = 80, OPITCH = OCOLS * 2 + 16, OBYTES = 32 * OPITCH;         // per-wave output transposition tile
   static constexpr int CPR = OCOLS / 8, NST = 32 * CPR / 64;                              // 10 chunks per row segment, 5 stores per lane
   // output tiles behind the ring while both fit (D = 2: 108 + 44 KiB), else in the ring's first slots after the last step
-  static constexpr bool OWN_OTILE = NS * SLOT + 8 * OBYTES <= 160 * 1024;
+  static constexpr bool OWN_OTILE = D >= 2 && NS * SLOT + 8 * OBYTES <= 160 * 1024;   // (D = 1: 72 KiB in all, two workgroups per CU)
   static constexpr int OTILE0 = OWN_OTILE ? NS * SLOT : 0;
   static constexpr int LDS_BYTES = OWN_OTILE ? NS * SLOT + 8 * OBYTES : NS * SLOT;
   static_assert(LDS_BYTES <= 160 * 1024 && 8 * OBYTES <= NS * SLOT && (32 * CPR) % 64 == 0, "m128 LDS / store mapping");
@@ -2387,10 +2387,17 @@ template <bool RES, int DEPTH, int LNMODE> static int launch_gemm_m128_one(const
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+template <int DEPTH> static int launch_gemm_m128_depth(const ConvGemmParams& p, hipStream_t stream) {
+  if (p.ln_stats) return p.residual ? launch_gemm_m128_one<true, DEPTH, 1>(p, stream) : launch_gemm_m128_one<false, DEPTH, 1>(p, stream);
+  if (p.ln_stats_out) return p.residual ? launch_gemm_m128_one<true, DEPTH, 2>(p, stream) : launch_gemm_m128_one<false, DEPTH, 2>(p, stream);
+  return p.residual ? launch_gemm_m128_one<true, DEPTH, 0>(p, stream) : launch_gemm_m128_one<false, DEPTH, 0>(p, stream);
+}
 static int launch_gemm_m128(const ConvGemmParams& p, hipStream_t stream) {
-  if (p.ln_stats) return p.residual ? launch_gemm_m128_one<true, 2, 1>(p, stream) : launch_gemm_m128_one<false, 2, 1>(p, stream);
-  if (p.ln_stats_out) return p.residual ? launch_gemm_m128_one<true, 2, 2>(p, stream) : launch_gemm_m128_one<false, 2, 2>(p, stream);
-  return p.residual ? launch_gemm_m128_one<true, 2, 0>(p, stream) : launch_gemm_m128_one<false, 2, 0>(p, stream);
+  // more than one round of tiles and few K steps each: two-slot ring (72 KiB), two workgroups per CU cover each other's
+  // prologue and epilogue
+  const long nb128 = (long)(p.M / 128) * (p.N / 160);
+  if (nb128 > 256 && p.K <= 1280 && p.M > 8192) return launch_gemm_m128_depth<1>(p, stream);
+  return launch_gemm_m128_depth<2>(p, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -3223,6 +3230,13 @@ int af_conv_rowpanel_kind(const ConvGemmParams& p, int batch) {
     // 768 against 384 = one and a half rounds; 59 -> 52 us)
     if (nb128 % 256 == 0 && nb128 <= 1024 && nb256 % 256 != 0) return 6;
   }
+  // [16384, 640] -> 640 of the 32x32 level (25 per forward, LayerNorm epilogues included): 512 half-size tiles on a two-slot
+  // ring, two workgroups per CU covering each other's prologue and epilogue, instead of 256 tiles of ten K steps each
+  // (25.1 -> 21.4 us; forward 15.45 -> 15.37 ms)
+  if (g_af_knobs.gemm_m128 && !geglu && !(p.ln_stats && p.ln_stats_out) && (!p.ln_stats || p.alpha == 1.0f) && !p.gn_ab && p.M % 128 == 0 &&
+      p.M > 8192 && p.M <= 16384 && p.N % 160 == 0 && p.K % 64 == 0 && p.K >= 256 && p.K <= 1280 && (!p.residual || p.ldr % 4 == 0) &&
+      p.ldo % 8 == 0 && ((__UINTPTR_TYPE__)p.out & 15) == 0 && (long)(p.M / 128) * (p.N / 160) == 512)
+    return 6;
   if (p.K == 1280)
     return (lvl >= 4 && p.N == 1280 && p.M >= 4096 && !geglu && p.alpha == 1.0f && !p.ln_stats && !p.ln_stats_out && !p.gn_ab &&
             (!p.residual || p.ldr % 4 == 0)) ? 3 : 0;

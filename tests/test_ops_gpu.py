@@ -256,7 +256,7 @@ def test_conv_gn_producer_refuses_sliced_k(gpu):
 
 @pytest.mark.parametrize("M,K,N,bias,res", [(4096, 1280, 1280, True, True), (4096, 1280, 1280, False, False), (4096, 5120, 1280, True, True),
                                             (2048, 1280, 1280, True, False), (8192, 640, 640, True, True), (4096, 256, 1600, True, False),
-                                            (4096, 1280, 3840, False, False)])
+                                            (4096, 1280, 3840, False, False), (16384, 640, 640, True, True), (16384, 320, 640, False, False)])
 def test_linear_m128_tile(gpu, report, knobs, M, K, N, bias, res):
     """gemm_m128_kernel (128 x 160 tile, both operands through an LDS-DMA ring): the few-row plain GEMMs of the 16x16 level,
     against torch and against the kernel it replaces (knob gemm_m128 = 0) on the same operands; 20 repeated launches must be
