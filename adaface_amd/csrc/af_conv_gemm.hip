@@ -3237,6 +3237,7 @@ int af_conv_rowpanel_kind(const ConvGemmParams& p, int batch) {
       p.M > 8192 && p.M <= 16384 && p.N % 160 == 0 && p.K % 64 == 0 && p.K >= 256 && p.K <= 1280 && (!p.residual || p.ldr % 4 == 0) &&
       p.ldo % 8 == 0 && ((__UINTPTR_TYPE__)p.out & 15) == 0 && (long)(p.M / 128) * (p.N / 160) == 512)
     return 6;
+  // (longer K or more rounds of this form measured slower: [16384, 2560] -> 640 58 -> 62-67 us, [65536, 1280] -> 320 72 -> 78 us)
   if (p.K == 1280)
     return (lvl >= 4 && p.N == 1280 && p.M >= 4096 && !geglu && p.alpha == 1.0f && !p.ln_stats && !p.ln_stats_out && !p.gn_ab &&
             (!p.residual || p.ldr % 4 == 0)) ? 3 : 0;
