@@ -3213,6 +3213,8 @@ int af_conv_rowpanel_kind(const ConvGemmParams& p, int batch) {
       p.Cin != p.K || p.ldc < p.Cin)
     return 0;
   const bool geglu = p.epilogue == AF_EPI_GEGLU;
+  // (the two-slot 128 x 160 form on [65536, 320] -> 320 instead of the row-panel kernel: 27.8 -> 26.0 us alone, but the forward,
+  // where most of these launches carry LayerNorm epilogues, 15.30 -> 15.37 ms: not taken)
   // (a consumer-side GroupNorm needs whole panels inside one sample: 256-row panels at K = 320, 128-row ones at K = 640)
   if (p.K == RowPanelCfg::K && p.M >= 128 * RowPanelCfg::BM) {
     if (p.gn_ab && (p.gn_hw <= 0 || p.gn_hw % RowPanelCfg::BM != 0)) return 0;
