@@ -2,7 +2,7 @@
 # usage: scripts/pmc_sq.sh <only>  -> SQ counters per dispatch for the GEMM/attention kernels of bench_shapes --only <only> --reps 1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/sq; mkdir -p gpurun_out/sq
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --kernel-include-regex "conv_gemm_pp_kernel|conv_gemm_kernel|conv3x3_halo|attn_kernel|rowpanel_kernel|xattn_short|attn_ring40" --output-format csv -d gpurun_out/sq -- python scripts/bench_shapes.py --only $1 --reps 1 > gpurun_out/sq/out.txt 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --kernel-include-regex "conv_gemm_pp_kernel|conv_gemm_kernel|conv3x3_halo|attn_kernel|rowpanel_kernel|xattn_short|attn_ring40|gemm_m128" --output-format csv -d gpurun_out/sq -- python scripts/bench_shapes.py --only $1 --reps 1 > gpurun_out/sq/out.txt 2>&1
 python - <<'PY'
 import csv, glob, collections
 rows=collections.OrderedDict()

@@ -3,7 +3,7 @@
 # when it is in the list (first dispatch of every (kernel, grid) pair of bench_shapes --only <only> --reps 1)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/sq2; mkdir -p gpurun_out/sq2
-rocprofv3 --pmc $2 --kernel-trace --kernel-include-regex "conv_gemm_pp_kernel|conv3x3_halo8|rowpanel_kernel|xattn_short|attn_ring40" --output-format csv -d gpurun_out/sq2 -- python scripts/bench_shapes.py --only $1 --reps 1 > gpurun_out/sq2/out.txt 2>&1
+rocprofv3 --pmc $2 --kernel-trace --kernel-include-regex "conv_gemm_pp_kernel|conv3x3_halo8|rowpanel_kernel|xattn_short|attn_ring40|gemm_m128" --output-format csv -d gpurun_out/sq2 -- python scripts/bench_shapes.py --only $1 --reps 1 > gpurun_out/sq2/out.txt 2>&1
 python - <<'PY'
 import csv, glob, collections
 rows=collections.OrderedDict()
