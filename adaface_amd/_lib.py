@@ -97,9 +97,6 @@ _SIGS = [
     ("af_gn_producer_launches", C.c_int64, []),
     ("af_attn_short_launches", C.c_int64, []),
     ("af_gn_consumer_launches", C.c_int64, []),
-    ("af_deferred_reduces", C.c_int64, []),
-    ("af_inlaunch_reduces", C.c_int64, []),
-    ("af_inlaunch_reduce_timeouts", C.c_int64, []),
     ("af_op_conv2d_fp8", C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 10 + [_P]),
     ("af_op_groupnorm_fp8", C.c_int, [_P, _P, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("af_op_layernorm_fp8", C.c_int, [_P, _P, _P, C.c_float, _P, C.c_int64, C.c_int, C.c_int, _P]),
@@ -161,8 +158,6 @@ def plan_counts(reset: bool = False) -> dict:
     out["gn_producer"] = int(lib.af_gn_producer_launches())
     out["attn_short"] = int(lib.af_attn_short_launches())
     out["gn_consumer"] = int(lib.af_gn_consumer_launches())
-    out["deferred_reduce"] = int(lib.af_deferred_reduces())
-    out["inlaunch_reduce"] = int(lib.af_inlaunch_reduces())
     if reset:
         lib.af_gemm_plan_counts_reset()
     return out

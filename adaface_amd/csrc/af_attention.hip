@@ -863,7 +863,7 @@ template <typename T, int DH> static int launch_attn(const AttnParams& p, int B,
     }
   }
   dim3 grid((p.Nq + 127) / 128, p.H, B);
-  if (C::BF && DH == 40 && g_af_knobs.attn_w4)
+  if (C::BF && DH == 40)
     hipLaunchKernelGGL((attn_kernel_w4<T, DH>), grid, dim3(256), C::LDS_BYTES, stream, p);
   else
     hipLaunchKernelGGL((attn_kernel<T, DH>), grid, dim3(256), C::LDS_BYTES, stream, p);
@@ -896,7 +896,7 @@ int af_launch_attn_short_pack(const void* v, int ldv, long bsv, int Nk, int H, i
     return -1;
   }
 }
-long g_af_attn_short_launches = 0;
+std::atomic<long> g_af_attn_short_launches{0};
 
 template <int DH> static int launch_xattn_short(const AttnParams& p, int B, hipStream_t stream) {
   const int nblk = (p.Nq + 31) / 32;

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -29,12 +30,14 @@ void af_set_error_msg(const char* fmt, ...);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): remember per device id where it has
 // been raised (one mask per kernel instantiation; a handle may live on any GPU of the node)
+// (distinct handles may be driven from distinct host threads: the mask is read and updated atomically; setting the attribute
+// twice is harmless)
 static inline int af_ensure_dynamic_lds(unsigned long long& done_mask, const void* fn, int bytes) {
   int dev = 0;
   HIP_CHECK_RET(hipGetDevice(&dev));
-  if (dev >= 0 && dev < 64 && ((done_mask >> dev) & 1ull)) return 0;
+  if (dev >= 0 && dev < 64 && ((__atomic_load_n(&done_mask, __ATOMIC_ACQUIRE) >> dev) & 1ull)) return 0;
   HIP_CHECK_RET(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  if (dev >= 0 && dev < 64) done_mask |= 1ull << dev;
+  if (dev >= 0 && dev < 64) __atomic_fetch_or(&done_mask, 1ull << dev, __ATOMIC_RELEASE);
   return 0;
 }
 
@@ -43,10 +46,11 @@ static inline int af_ensure_dynamic_lds(unsigned long long& done_mask, const voi
 // quote ONE kernel (conv_gemm_pp_kernel<160, true>, the 3x3 convolutions) with its own launch count and duration
 enum { AF_K_CONV_GEMM = 0, AF_K_ATTENTION = 1, AF_K_GROUPNORM = 2, AF_K_LAYERNORM = 3, AF_K_OTHER = 4,
        AF_K_PP160_GATHER = 5, AF_K_PP160_PLAIN = 6, AF_K_PP128 = 7, AF_K_PP_FP8 = 8, AF_K_HALO8 = 9, AF_K_COUNT = 10 };
+// (process-wide diagnostics, updated by every launch: atomics, since distinct handles may be used from distinct host threads)
 extern int g_af_prof_enabled;
 extern int g_af_prof_stride;              // bracket only every stride-th launch of a class (>= 1)
-extern long g_af_prof_seen[AF_K_COUNT];   // launches seen per class since af_prof_reset
-extern double g_af_flops_issued;          // FLOPs handed to GEMM / conv / attention launches since af_flops_issued(reset): what the
+extern std::atomic<long> g_af_prof_seen[AF_K_COUNT];   // launches seen per class since af_prof_reset
+extern std::atomic<double> g_af_flops_issued;          // FLOPs handed to GEMM / conv / attention launches since af_flops_issued(reset): what the
                                           // path EXECUTES (phase-decomposed upsamplers and the shared CFG prefix spend fewer
                                           // than the reference's algorithm; bench.py reports both fractions)
 void af_prof_begin_impl(int cls, hipStream_t s, double flops, double bytes);
@@ -55,10 +59,13 @@ struct AfProfScope {
   hipStream_t s;
   bool on;
   AfProfScope(int cls, hipStream_t s_, double flops, double bytes) : s(s_), on(((g_af_prof_enabled >> cls) & 1) != 0) {
-    g_af_flops_issued += flops;
+    if (flops != 0.0) {
+      double cur = g_af_flops_issued.load(std::memory_order_relaxed);
+      while (!g_af_flops_issued.compare_exchange_weak(cur, cur + flops, std::memory_order_relaxed)) {}
+    }
     // an event pair costs ~9 us of stream time on MI355X (measured: bracketing every GEMM and attention launch slowed
     // the 50-step batch by 10 %), so the bench samples every stride-th launch of a class instead of all of them
-    if (on) on = (g_af_prof_seen[cls]++ % g_af_prof_stride) == 0;
+    if (on) on = (g_af_prof_seen[cls].fetch_add(1, std::memory_order_relaxed) % g_af_prof_stride) == 0;
     if (on) af_prof_begin_impl(cls, s, flops, bytes);
   }
   ~AfProfScope() {
@@ -80,13 +87,10 @@ struct AfKnobs {
   int gemm_groupm;          // AF_GEMM_GROUPM          >= 1: force the grouped tile order
   int gemm_dma;             // AF_GEMM_DMA             0 / 1: force register / LDS-DMA staging in the four-wave kernel
   int pp_direct;            // AF_PP_DIRECT            0 / 1: force the LDS / direct epilogue of the ping-pong kernel
-  int attn_w4;              // AF_ATTN_W4              0 = dh-40 attention without the four-waves-per-SIMD cap
   int attn_ring;            // AF_ATTN_RING            0 = dh-40 bf16 attention on the four-wave kernel instead of the ring kernel
   int gn_small;             // AF_GN_SMALL             0 = no single-launch GroupNorm for small maps
-  int gn_fold;              // AF_GN_FOLD              0 = separate GroupNorm finalize pass
   int conv_tap_inner;       // AF_CONV_TAP_INNER       0 = ping-pong convs walk K tap-outermost (the round-1 order)
-  int ln_fuse;              // AF_LN_FUSE              0 = stand-alone LayerNorm kernels in front of the transformer GEMMs; 3 = folded at
-                            //                         the 16x16 level as well (128 x 160 tile GEMM epilogues; measured neutral)
+  int ln_fuse;              // AF_LN_FUSE              0 = stand-alone LayerNorm kernels in front of the transformer GEMMs
   int geglu_rowpanel;       // AF_GEGLU_ROWPANEL       row-panel kernel (K = 320, >= 32768 rows): 0 = never, 1 = GEGLU only, 2 = the plain
                             //                         GEMMs of the 64x64-level transformers too, 3 = and its K = 640 form (GEGLU and
                             //                         q / k / v of the 32x32 level, >= 16384 rows), 4 = and the K = 1280 form
@@ -99,18 +103,10 @@ struct AfKnobs {
   int pp_sched;             // AF_PP_SCHED             eight-wave kernel: 0 = round-1 compute phase (two K halves, a full LDS drain
                             //                         after each), 1 = block-ordered compute phase, 2 = merged (no staging phase)
   int attn_short;           // AF_ATTN_SHORT           0 = cross-attention (<= 96 keys) stays on the flash kernels
-  int rowpanel_deep;        // AF_ROWPANEL_DEEP        0 = row-panel kernels keep the round-2 weight ring (3 slots, prefetch distance 2)
   int gemm_m128;            // AF_GEMM_M128            0 = no 128 x 160 tile GEMM for the few-row plain GEMMs (16x16 level)
   int small_m_tile64;       // AF_SMALL_M_TILE64       0 = GEMMs with <= 1024 rows and K <= 2048 keep the cost model's tile / K slices
-  int gn_reduce;            // AF_GN_REDUCE            1 = a sliced-K ResBlock conv1 on a small map leaves its reduce to the single-launch
-                            //                         GroupNorm that follows it.  Default 0: bit-identical, but measured 0.1 ms per forward
-                            //                         SLOWER (512 workgroups summing 42 MB of slabs against the reduce kernel's 4096)
   int gn_consumer;          // AF_GN_CONSUMER          0 = the SpatialTransformer's GroupNorm always runs its own apply pass (never
-                            //                         in the prologue of a row-panel proj_in)
-  int splitk_inlaunch;      // AF_SPLITK_INLAUNCH      1 = sliced-K launches whose whole grid is resident reduce their slabs themselves
-                            //                         (pp_inlaunch_reduce; bit-identical, 25 fewer launches per forward).  Default 0:
-                            //                         measured 15.72 vs 15.69 ms per forward -- the slabs must go through memory
-                            //                         (the slices of a tile sit on different XCDs), which costs what the launch saved
+                            //                         in the prologue of a row-panel proj_in, 64x64 level)
   int plan_log;             // AF_PLAN_LOG             1 = one stderr line per GEMM / convolution launch: shape, tile, K slices (lab)
 };
 extern AfKnobs g_af_knobs;
@@ -325,14 +321,6 @@ struct ConvGemmParams {
   // would have stored
   const float* gn_ab;
   int gn_hw;
-  // split-K launch whose slabs the CONSUMER reduces (a single-launch GroupNorm, af_launch_groupnorm_slabs): no reduce launch,
-  // p.out is not written
-  int defer_reduce;
-  // split-K launch that reduces its own slabs (set by af_launch_conv_gemm, never by callers): the S workgroups of a tile meet
-  // on sk_sync[2 * tile] and each finishes 1 / S of the tile's rows; no reduce launch.  Only when every workgroup of the grid
-  // is resident at once (grid <= compute units).  sk_sync: zeroed words owned by the library, one set per stream
-  unsigned* sk_sync;
-  int sk_inlaunch;
 };
 
 struct AfGemmPlan {

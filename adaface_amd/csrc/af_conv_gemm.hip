@@ -37,7 +37,6 @@
 
 #include <cstdlib>
 #include <cstring>
-#include <map>
 #include <mutex>
 #include <type_traits>
 
@@ -491,35 +490,13 @@ __device__ __forceinline__ void pp_wait_lgkm0() {
 }
 
 // One output quad of a sliced-K launch: out[m][n .. n+3] = T(sum_z slab[z][m][n..] + bias + rowbias + residual), slabs summed
-// in slice order.  The ONLY place this arithmetic lives: splitk_reduce_kernel and the in-launch reduction both call it, so the
-// two are bit-identical by construction.  AGENT: the slabs were written by other workgroups of THIS launch, possibly on
-// another XCD (own L2): they are read with sc0 sc1 loads (from memory, past the L2s), as they were stored.
-constexpr int AF_AUX_AGENT = 17;   // buffer-instruction cache policy sc0 | sc1
-template <typename T, bool AGENT>
+// in slice order (splitk_reduce_kernel).
+template <typename T>
 __device__ __forceinline__ void splitk_reduce_quad(const ConvGemmParams& p, int m, int n) {
   const float* ws = reinterpret_cast<const float*>(p.ws);
   f32x4 a;
-  if constexpr (AGENT) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws), 0, (int)0xFFFFFFF0u, 0x00020000);
-    const unsigned off = (unsigned)(((long)m * p.N + n) * 4), slab_b = (unsigned)((long)p.M * p.N * 4);
-    // eight slabs in flight (memory latency, not bandwidth, is the cost here); slices past the last one are out-of-range
-    // offsets (zeros, no branch) and are not added (x + 0 would turn -0 into +0: not the other path's bits)
-    for (int z0 = 0; z0 < p.splitk; z0 += 8) {
-      f32x4 part[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        part[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            rs, z0 + k < p.splitk ? off + (unsigned)(z0 + k) * slab_b : 0xFFFFFFFFu, 0, AF_AUX_AGENT));
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (z0 + k == 0) a = part[0];
-        else if (z0 + k < p.splitk) a += part[k];
-      }
-    }
-  } else {
-    a = *reinterpret_cast<const f32x4*>(ws + (long)m * p.N + n);
-    for (int zz = 1; zz < p.splitk; ++zz) a += *reinterpret_cast<const f32x4*>(ws + ((long)zz * p.M + m) * p.N + n);
-  }
+  a = *reinterpret_cast<const f32x4*>(ws + (long)m * p.N + n);
+  for (int zz = 1; zz < p.splitk; ++zz) a += *reinterpret_cast<const f32x4*>(ws + ((long)zz * p.M + m) * p.N + n);
   float v[4] = {a[0], a[1], a[2], a[3]};
   if (p.bias) {
     const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
@@ -542,56 +519,6 @@ __device__ __forceinline__ void splitk_reduce_quad(const ConvGemmParams& p, int 
   for (int e = 0; e < 4; ++e) o.e[e] = from_f32<T>(v[e]);
   o.store(reinterpret_cast<T*>(p.out) + (long)m * p.ldo + n);
 }
-// slab store of a launch that reduces in-launch: written through to memory (see splitk_reduce_quad)
-__device__ __forceinline__ void slab_store_agent(float* slab_base, long elem_off, f32x4 v) {
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab_base, 0, (int)0xFFFFFFF0u, 0x00020000);
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pp_u32x4, v), rs, (unsigned)(elem_off * 4), 0, AF_AUX_AGENT);
-}
-
-// In-launch reduction of a sliced-K tile (ConvGemmParams::sk_inlaunch; 512 threads, called by every thread of the workgroup
-// after its slab stores).  The S workgroups of tile `tile` (one per K slice zk) are all resident (the launcher checks grid <=
-// compute units), so waiting for each other cannot deadlock:
-//   slab stores complete (written THROUGH to memory, slab_store_agent: the slices of a tile may sit on different XCDs with
-//   their own L2; a release fence instead -- buffer_wbl2 by every wave of 32 workgroups per XCD -- cost 60 us per launch)
-//   -> arrive on sk_sync[2 * tile] -> wait until all S arrived (bounded: a miss is counted in sk_sync[AF_SK_TIMEOUT_WORD],
-//   never a hang) -> this workgroup finishes rows [zk, zk + 1) * 256 / S of the tile through splitk_reduce_quad<T, true>
-//   (loads past the L2s) -> leave on sk_sync[2 * tile + 1]; the last to leave zeroes both words for the next launch.
-constexpr int AF_SK_SYNC_TILES = 256, AF_SK_TIMEOUT_WORD = 2 * AF_SK_SYNC_TILES, AF_SK_SYNC_WORDS = AF_SK_TIMEOUT_WORD + 2;
-template <typename T, int BN>
-__device__ __forceinline__ void pp_inlaunch_reduce(const ConvGemmParams& p, int tile, int m0, int n0, int zk, int tid) {
-  const unsigned S = (unsigned)p.splitk;
-  unsigned* cnt = p.sk_sync + 2 * tile;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores have reached memory
-  __syncthreads();
-  if (tid == 0) {
-    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int spins = 0;
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) {
-      if (++spins > (1 << 20)) {          // ~0.5 s: only if a slice never became resident
-        __hip_atomic_fetch_add(p.sk_sync + AF_SK_TIMEOUT_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-  }
-  __syncthreads();
-  const int R = (256 + (int)S - 1) / (int)S;
-  const int r0 = zk * R, r1 = min(256, r0 + R);
-  constexpr int QPR = BN / 4;
-  for (int idx = tid; idx < (r1 - r0) * QPR; idx += 512) {
-    const int row = idx / QPR, q = idx - row * QPR;
-    const int m = m0 + r0 + row, n = n0 + 4 * q;
-    if (m < p.M && n < p.N) splitk_reduce_quad<T, true>(p, m, n);
-  }
-  if (tid == 0) {
-    const unsigned left = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (left == S - 1) {                  // every slice is past its wait: nobody reads cnt[0] any more
-      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 // Epilogue of the eight-wave kernels (shared by conv_gemm_pp_kernel and conv3x3_halo8_kernel): bias / LayerNorm / GEGLU on
 // the accumulators, then either straight from the registers or through an fp32 LDS tile in two 128-row passes.
 // Accumulator layout: wave (g, wq) holds rows m0 + wq * 64 + j * 16 + (lane & 15), columns n0 + g * HN + i * 16 +
@@ -744,8 +671,7 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           if (i >= nblk) continue;
-          if (p.sk_inlaunch) slab_store_agent(slab, (long)m * p.N + cbase + i * 16, acc[i][j]);
-          else *reinterpret_cast<f32x4*>(slab + (long)m * p.N + cbase + i * 16) = acc[i][j];
+          *reinterpret_cast<f32x4*>(slab + (long)m * p.N + cbase + i * 16) = acc[i][j];
         }
         continue;
       }
@@ -808,7 +734,6 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
         }
       }
     }
-    if (slab && p.sk_inlaunch) pp_inlaunch_reduce<T, BN>(p, (m0 >> 8) * (p.N / BN) + tn, m0, n0, zk, tid);
     return;
   }
   constexpr int ITEMS = BN / 32;                    // 8-column vectors per thread and pass (GEGLU: half of them)
@@ -863,13 +788,8 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
       const int m = im[it], n = in_[it];
       if (m < 0) continue;
       if (slab) {
-        if (p.sk_inlaunch) {
-          slab_store_agent(slab, (long)m * p.N + n, f32x4{v[it][0], v[it][1], v[it][2], v[it][3]});
-          slab_store_agent(slab, (long)m * p.N + n + 4, f32x4{v[it][4], v[it][5], v[it][6], v[it][7]});
-        } else {
-          *reinterpret_cast<float4*>(slab + (long)m * p.N + n) = float4{v[it][0], v[it][1], v[it][2], v[it][3]};
-          *reinterpret_cast<float4*>(slab + (long)m * p.N + n + 4) = float4{v[it][4], v[it][5], v[it][6], v[it][7]};
-        }
+        *reinterpret_cast<float4*>(slab + (long)m * p.N + n) = float4{v[it][0], v[it][1], v[it][2], v[it][3]};
+        *reinterpret_cast<float4*>(slab + (long)m * p.N + n + 4) = float4{v[it][4], v[it][5], v[it][6], v[it][7]};
         continue;
       }
 #pragma unroll
@@ -890,7 +810,6 @@ __device__ __forceinline__ void pp_epilogue(const ConvGemmParams& p, f32x4 (&acc
       }
     }
   }
-  if (slab && p.sk_inlaunch) pp_inlaunch_reduce<T, BN>(p, (m0 >> 8) * (p.N / BN) + tn, m0, n0, zk, tid);
 }
 
 template <int N> __device__ __forceinline__ void pp_wait_lgkm() {   // counted: LDS reads return in order
@@ -2073,14 +1992,12 @@ static int launch_rowpanel_depth(const ConvGemmParams& p, hipStream_t stream) {
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-// ring depth: the deepest the form's LDS allows (see RowPanelCfgT), or the round-2 depth of 2 with knob rowpanel_deep = 0
+// ring depth: the deepest the form's LDS allows (see RowPanelCfgT).  (Measured against the round-2 depth of 2: nothing, 15.596 vs
+// 15.631 ms per forward -- the knob that selected between them left in round 4.)
 template <bool GEGLU, int LNMODE, bool RES, int KC = 5, int MJ = 2>
 static int launch_rowpanel_one(const ConvGemmParams& p, hipStream_t stream) {
   constexpr int DEEP = GEGLU ? 5 : (MJ == 1 ? 4 : 2);
-  if constexpr (DEEP != 2) {
-    if (g_af_knobs.rowpanel_deep) return launch_rowpanel_depth<GEGLU, LNMODE, RES, KC, MJ, DEEP>(p, stream);
-  }
-  return launch_rowpanel_depth<GEGLU, LNMODE, RES, KC, MJ, 2>(p, stream);
+  return launch_rowpanel_depth<GEGLU, LNMODE, RES, KC, MJ, DEEP>(p, stream);
 }
 // (k640: the 32x32-level form, K = 640, 16 rows per wave)
 static int launch_geglu_rowpanel(const ConvGemmParams& p, hipStream_t stream, bool k640 = false) {
@@ -2629,7 +2546,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvGemmParams
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nq; i += (long)gridDim.x * 256) {
     const int m = (int)(i / (p.N >> 2));
     const int n = (int)(i - (long)m * (p.N >> 2)) * 4;
-    splitk_reduce_quad<T, false>(p, m, n);
+    splitk_reduce_quad<T>(p, m, n);
   }
 }
 
@@ -2737,53 +2654,16 @@ int af_launch_cast_fp8(const void* x, void* y, long n, float mul, hipStream_t st
   return 0;
 }
 
-AfGemmPlan g_af_last_plan = {0, 1, 0, 0, 1};
-long g_af_gn_consumer_launches = 0;
-long g_af_deferred_reduces = 0;       // sliced-K launches whose reduce was left to the GroupNorm that consumes them
-long g_af_inlaunch_reduces = 0;       // sliced-K launches that reduced their slabs themselves (pp_inlaunch_reduce)
-
-// sk_sync words of the in-launch reduction: one zeroed set per (device, stream) -- launches of one stream are ordered, launches
-// of two streams may overlap and must not share arrival counters.  Never freed (a few KB per stream a process ever used).
-static std::mutex g_sk_mu;
-static std::map<std::pair<int, hipStream_t>, unsigned*> g_sk_bufs;
-static int g_sk_cus[16] = {0};
-static unsigned* sk_sync_for(hipStream_t stream, int* n_cu) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  std::lock_guard<std::mutex> lk(g_sk_mu);
-  if (!g_sk_cus[dev] && hipDeviceGetAttribute(&g_sk_cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return nullptr;
-  *n_cu = g_sk_cus[dev];
-  auto key = std::make_pair(dev, stream);
-  auto it = g_sk_bufs.find(key);
-  if (it != g_sk_bufs.end()) return it->second;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;   // (no allocation inside a capture)
-  unsigned* b = nullptr;
-  if (hipMalloc(&b, AF_SK_SYNC_WORDS * sizeof(unsigned)) != hipSuccess) return nullptr;
-  if (hipMemset(b, 0, AF_SK_SYNC_WORDS * sizeof(unsigned)) != hipSuccess) { hipFree(b); return nullptr; }
-  g_sk_bufs[key] = b;
-  return b;
-}
-// waits that gave up (a slice of an in-launch reduction never arrived: its outputs are wrong), summed over this process's
-// streams; synchronises the device.  Tests, smoke() and bench.py assert 0.
-long af_sk_timeouts_total() {
-  std::lock_guard<std::mutex> lk(g_sk_mu);
-  long tot = 0;
-  for (auto& kv : g_sk_bufs) {
-    unsigned v = 0;
-    int cur = 0;
-    hipGetDevice(&cur);
-    hipSetDevice(kv.first.first);
-    if (hipMemcpy(&v, kv.second + AF_SK_TIMEOUT_WORD, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) tot += v;
-    hipSetDevice(cur);
-  }
-  return tot;
-}
+static std::mutex g_last_plan_mu;
+static AfGemmPlan g_af_last_plan = {0, 1, 0, 0, 1};
+void af_set_last_plan(const AfGemmPlan& pl) { std::lock_guard<std::mutex> lk(g_last_plan_mu); g_af_last_plan = pl; }
+AfGemmPlan af_get_last_plan() { std::lock_guard<std::mutex> lk(g_last_plan_mu); return g_af_last_plan; }
+std::atomic<long> g_af_gn_consumer_launches{0};
 // launches since af_gemm_plan_counts_reset: [0..5] by tile (implicit-GEMM / ping-pong kernels), [6] LDS-halo kernel,
 // [7] launches that sliced K (counted in their tile's slot as well), [8] / [9] ping-pong launches with the LayerNorm
 // consumer / statistics-producer epilogue, [10] ping-pong launches with fp8 operands, [11] eight-wave halo launches
 // (counted under tile 5 as well), [12] row-panel GEGLU launches (counted under their planned tile as well)
-long g_af_plan_counts[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [13]: phase-decomposed upsampled convolutions, [14]: GroupNorm-statistics producers
+std::atomic<long> g_af_plan_counts[15] = {};   // [13]: phase-decomposed upsampled convolutions, [14]: GroupNorm-statistics producers
 
 
 // tile: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64
@@ -3052,7 +2932,7 @@ static int launch_conv_gemm_fp8(ConvGemmParams p, hipStream_t stream, const AfGe
   if (pl.splitk > 1 && !ws) pl.splitk = 1;
   p.splitk = pl.splitk;
   p.ws = ws;
-  g_af_last_plan = pl;
+  af_set_last_plan(pl);
   g_af_plan_counts[10] += 1;
   if (pl.splitk > 1) g_af_plan_counts[7] += 1;
   {
@@ -3184,7 +3064,7 @@ static int launch_up_phase4(ConvGemmParams p, hipStream_t stream) {
   pl.tile = bn == 160 ? 5 : 4; pl.splitk = 1; pl.ws_bytes = 0; pl.halo_tw = 0; pl.group_m = 1;
   plan_group_m(pl, p);
   p.group_m = pl.group_m > 0 ? pl.group_m : 1;
-  g_af_last_plan = pl;
+  af_set_last_plan(pl);
   g_af_plan_counts[13] += 1;
   AfProfScope prof(bn == 160 ? AF_K_PP160_GATHER : AF_K_PP128, stream, 2.0 * p.M * (double)p.N * p.K * 4,
                    ((double)p.M * p.Cin + 4.0 * p.N * p.K + 4.0 * p.M * p.N) * 2);
@@ -3244,11 +3124,9 @@ int af_conv_rowpanel_kind(const ConvGemmParams& p, int batch) {
     return (lvl >= 4 && p.N == 1280 && p.M >= 4096 && !geglu && p.alpha == 1.0f && !p.ln_stats && !p.ln_stats_out && !p.gn_ab &&
             (!p.residual || p.ldr % 4 == 0)) ? 3 : 0;
   if (p.K == 640 && lvl >= 3 && p.M >= 16384 && !p.residual) {
-    if (p.gn_ab) {
-      // proj_in of a 32x32-level transformer with its GroupNorm applied in the prologue: N = 640 is short for this kernel (the
-      // tiled one measures ahead on the bare GEMM); knob gn_consumer >= 2 only
-      return (g_af_knobs.gn_consumer >= 2 && !geglu && p.gn_hw > 0 && p.gn_hw % 128 == 0 && p.N % 160 == 0 && p.alpha == 1.0f && !p.ln_stats) ? 5 : 0;
-    }
+    // (proj_in of a 32x32-level transformer with its GroupNorm applied in this kernel's prologue was built in round 3 and measured
+    // slower -- N = 640 is short for this kernel, the tiled one is ahead on the bare GEMM by what the pass costs: 15.64 vs 15.60 ms)
+    if (p.gn_ab) return 0;
     if (p.ln_stats_out) return 0;
     if (geglu) return p.N % 128 == 0 ? 4 : 0;
     return (p.N % 160 == 0 && p.N >= 1920 && p.alpha == 1.0f) ? 5 : 0;
@@ -3296,14 +3174,9 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   }
   AfGemmPlan pl = plan ? *plan : af_plan_conv_gemm(p, batch, (int)sizeof(T));
   if (pl.splitk > 1 && !ws) pl.splitk = 1;  // no workspace supplied: fall back to one slice
-  if (p.defer_reduce && (pl.splitk <= 1 || p.residual || batch != 1 || p.epilogue != AF_EPI_NONE || p.ln_stats || p.ln_stats_out || p.gn_stats_out)) {
-    af_set_error_msg("conv_gemm: defer_reduce on a launch that does not slice K (or carries a residual / fused epilogue)");
-    return -1;
-  }
-  if (p.defer_reduce) g_af_deferred_reduces += 1;
   if constexpr (sizeof(T) == 2) {
     // the 128 x 160 tile GEMM fills the chip in one K slice where the 256-row tile was planned over two
-    if (pl.splitk > 1 && !p.defer_reduce) {
+    if (pl.splitk > 1) {
       ConvGemmParams q = p;
       q.splitk = 1;
       if (af_conv_rowpanel_kind(q, batch) == 6) pl.splitk = 1;
@@ -3311,30 +3184,10 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
   }
   p.splitk = pl.splitk;
   p.ws = ws;
-  p.sk_sync = nullptr;
-  p.sk_inlaunch = 0;
-  if constexpr (sizeof(T) == 2) {
-    // the S workgroups of a tile reduce it between them when the whole grid is resident at once (eight-wave kernels, one
-    // workgroup per compute unit): no reduce launch
-    if (pl.splitk > 1 && !p.defer_reduce && g_af_knobs.splitk_inlaunch && batch == 1 && !p.phase4 && (pl.tile == 4 || pl.tile == 5) &&
-        (pl.halo_tw == 0 || pl.halo_tw == 256) && p.epilogue == AF_EPI_NONE && !p.ln_stats && !p.ln_stats_out && !p.gn_stats_out && !p.fp8) {
-      const int bn = pl.tile == 4 ? 128 : 160;
-      const long tiles = (long)((p.M + 255) / 256) * (p.N / bn);
-      int n_cu = 0;
-      if (p.N % bn == 0 && tiles <= AF_SK_SYNC_TILES) {
-        unsigned* sk = sk_sync_for(stream, &n_cu);
-        if (sk && tiles * pl.splitk <= n_cu) {
-          p.sk_sync = sk;
-          p.sk_inlaunch = 1;
-          g_af_inlaunch_reduces += 1;
-        }
-      }
-    }
-  }
-  g_af_last_plan = pl;
+  af_set_last_plan(pl);
   if (g_af_knobs.plan_log)
-    fprintf(stderr, "[af plan] M=%ld N=%d K=%d ks=%d stride=%d up=%d HoWo=%dx%d batch=%d tile=%d halo=%d splitk=%d%s rowpanel=%d res=%d geglu=%d ln=%d\n",
-            (long)p.M, p.N, p.K, p.ks, p.stride, p.up, p.Ho, p.Wo, batch, pl.tile, pl.halo_tw, pl.splitk, p.sk_inlaunch ? "(in-launch)" : "", af_conv_rowpanel_kind(p, batch),
+    fprintf(stderr, "[af plan] M=%ld N=%d K=%d ks=%d stride=%d up=%d HoWo=%dx%d batch=%d tile=%d halo=%d splitk=%d rowpanel=%d res=%d geglu=%d ln=%d\n",
+            (long)p.M, p.N, p.K, p.ks, p.stride, p.up, p.Ho, p.Wo, batch, pl.tile, pl.halo_tw, pl.splitk, af_conv_rowpanel_kind(p, batch),
             p.residual ? 1 : 0, p.epilogue == AF_EPI_GEGLU ? 1 : 0, (p.ln_stats || p.ln_stats_out) ? 1 : 0);
   g_af_plan_counts[(pl.halo_tw && pl.halo_tw != 256) ? 6 : (pl.tile >= 0 && pl.tile < 6 ? pl.tile : 0)] += 1;
   if (pl.halo_tw == 256) g_af_plan_counts[11] += 1;
@@ -3402,7 +3255,7 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
       return -1;
     }
     if (rc) return rc;
-    if (p.splitk > 1 && !p.defer_reduce && !p.sk_inlaunch) {
+    if (p.splitk > 1) {
       const long nq = (long)p.M * (p.N >> 2);
       unsigned blocks = (unsigned)((nq + 255) / 256);
       if (blocks > 4096) blocks = 4096;
@@ -3433,7 +3286,7 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
     default: rc = launch_cfg<T, 64, 64>(p, batch, stream); break;
   }
   if (rc) return rc;
-  if (p.splitk > 1 && !p.defer_reduce && !p.sk_inlaunch) {
+  if (p.splitk > 1) {
     const long nq = (long)p.M * (p.N >> 2);
     unsigned blocks = (unsigned)((nq + 255) / 256);
     if (blocks > 4096) blocks = 4096;

@@ -12,7 +12,7 @@ template <typename T> int af_launch_attention(const AttnParams& p, int B, int dh
 template <typename T> long af_attn_short_pack_elems(int B, int H, int dh, int Nk);
 template <typename T>
 int af_launch_attn_short_pack(const void* v, int ldv, long bsv, int Nk, int H, int dh, int B, void* vt, hipStream_t stream);
-extern long g_af_attn_short_launches;
+extern std::atomic<long> g_af_attn_short_launches;
 
 size_t af_gn_workspace_bytes(int B, int HW);
 template <typename T>
@@ -20,17 +20,6 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
                         const float* beta, float eps, int silu, void* y, long y_bs, int ldy, void* workspace,
                         hipStream_t stream, float fp8_mul = 0.f,    // fp8_mul != 0: y is e4m3 bytes of result * fp8_mul
                         const float* pre_partial = nullptr, int pre_npart = 0);   // statistics already summed by the producer
-// GroupNorm (+SiLU) of a convolution output left as fp32 split-K slabs ws[splitk][M][N] (ConvGemmParams::defer_reduce): the
-// single-launch kernel forms every element as splitk_reduce_kernel would have stored it; af_gn_small_ok says whether a shape
-// has that kernel
-bool af_gn_small_ok(int HW, int Cn, int elem_size);
-template <typename T>
-int af_launch_groupnorm_slabs(const float* ws, int splitk, int M, int N, const float* bias, const void* rowbias, int ldrb, int B,
-                              int HW, int Cn, const float* gamma, const float* beta, float eps, int silu, void* y, long y_bs,
-                              int ldy, hipStream_t stream, float fp8_mul = 0.f);
-extern long g_af_deferred_reduces;
-extern long g_af_inlaunch_reduces;
-long af_sk_timeouts_total();
 // GroupNorm reduced to its per-sample affine map ab_out [B][2][Cn] (scale, shift) for a consumer that applies it itself
 // (ConvGemmParams::gn_ab): statistics pass (unless pre_partial) + fold, no pass that writes the normalised tensor
 template <typename T>
@@ -99,9 +88,10 @@ int af_launch_ln_fold(const void* W, void* Wf, const float* gamma, const float* 
 int af_launch_ln_finalize(const float* part, int parts, int M, int count, float eps, float* out, hipStream_t s);
 
 // plan of the most recent af_launch_conv_gemm (diagnostics, af_last_gemm_plan)
-extern AfGemmPlan g_af_last_plan;
-extern long g_af_plan_counts[15];
-extern long g_af_gn_consumer_launches;
+void af_set_last_plan(const AfGemmPlan& pl);
+AfGemmPlan af_get_last_plan();
+extern std::atomic<long> g_af_plan_counts[15];
+extern std::atomic<long> g_af_gn_consumer_launches;
 int af_launch_up_phase4_weights(const void* w3, int rows, int cin, int ldw3, void* w4, hipStream_t stream);
 // fp8 (e4m3) twin of a repacked bf16 weight (K in 64-channel units, power-of-two row scales) / saturating bf16 -> e4m3 cast
 int af_launch_quant_weight_fp8(const void* w, int rows, int ldw, int cin_pad, int ks, void* w8, int k8, unsigned char* sc,

@@ -50,24 +50,24 @@ AfKnobs g_af_knobs = {
     knob_env("AF_SPLITK_TARGET", 320), knob_env("AF_CONV_HALO", 1),       knob_env("AF_GEMM_PP", 1),
     knob_env("AF_GEMM_PP_GEGLU_MINKT", 0), knob_env("AF_GEMM_PP_MINFILL", 50), knob_env("AF_GEMM_TILE", -1),
     knob_env("AF_GEMM_SPLITK", -1),    knob_env("AF_GEMM_GROUPM", -1),    knob_env("AF_GEMM_DMA", -1),
-    knob_env("AF_PP_DIRECT", -1),      knob_env("AF_ATTN_W4", 1),         knob_env("AF_ATTN_RING", 1),
-    knob_env("AF_GN_SMALL", 1),        knob_env("AF_GN_FOLD", 1),         knob_env("AF_CONV_TAP_INNER", 1),
+    knob_env("AF_PP_DIRECT", -1),      knob_env("AF_ATTN_RING", 1),
+    knob_env("AF_GN_SMALL", 1),        knob_env("AF_CONV_TAP_INNER", 1),
     knob_env("AF_LN_FUSE", 1),         knob_env("AF_GEGLU_ROWPANEL", 4), knob_env("AF_CONV_HALO8", 1), knob_env("AF_CONV_FAST_TAPS", 1),
     knob_env("AF_PP_STAGGER", 1),      knob_env("AF_GN_PRODUCER", 1),     knob_env("AF_CONV_UP_PHASE4", 1),
-    knob_env("AF_PP_SCHED", 2),        knob_env("AF_ATTN_SHORT", 1),      knob_env("AF_ROWPANEL_DEEP", 1),
-    knob_env("AF_GEMM_M128", 1),       knob_env("AF_SMALL_M_TILE64", 1),  knob_env("AF_GN_REDUCE", 0),       knob_env("AF_GN_CONSUMER", 1),
-    knob_env("AF_SPLITK_INLAUNCH", 0), knob_env("AF_PLAN_LOG", 0)};
+    knob_env("AF_PP_SCHED", 2),        knob_env("AF_ATTN_SHORT", 1),
+    knob_env("AF_GEMM_M128", 1),       knob_env("AF_SMALL_M_TILE64", 1),  knob_env("AF_GN_CONSUMER", 1),
+    knob_env("AF_PLAN_LOG", 0)};
 static const AfKnobs g_af_knobs_initial = g_af_knobs;
 static int* knob_slot(const char* name) {
   static const struct { const char* n; int AfKnobs::*m; } tab[] = {
       {"splitk_target", &AfKnobs::splitk_target}, {"conv_halo", &AfKnobs::conv_halo}, {"gemm_pp", &AfKnobs::gemm_pp},
       {"gemm_pp_geglu_minkt", &AfKnobs::gemm_pp_geglu_minkt}, {"gemm_pp_minfill", &AfKnobs::gemm_pp_minfill},
       {"gemm_tile", &AfKnobs::gemm_tile}, {"gemm_splitk", &AfKnobs::gemm_splitk}, {"gemm_groupm", &AfKnobs::gemm_groupm},
-      {"gemm_dma", &AfKnobs::gemm_dma}, {"pp_direct", &AfKnobs::pp_direct}, {"attn_w4", &AfKnobs::attn_w4}, {"attn_ring", &AfKnobs::attn_ring},
-      {"gn_small", &AfKnobs::gn_small}, {"gn_fold", &AfKnobs::gn_fold}, {"conv_tap_inner", &AfKnobs::conv_tap_inner}, {"ln_fuse", &AfKnobs::ln_fuse},
+      {"gemm_dma", &AfKnobs::gemm_dma}, {"pp_direct", &AfKnobs::pp_direct}, {"attn_ring", &AfKnobs::attn_ring},
+      {"gn_small", &AfKnobs::gn_small}, {"conv_tap_inner", &AfKnobs::conv_tap_inner}, {"ln_fuse", &AfKnobs::ln_fuse},
       {"geglu_rowpanel", &AfKnobs::geglu_rowpanel}, {"conv_halo8", &AfKnobs::conv_halo8}, {"conv_fast_taps", &AfKnobs::conv_fast_taps}, {"pp_stagger", &AfKnobs::pp_stagger}, {"gn_producer", &AfKnobs::gn_producer}, {"conv_up_phase4", &AfKnobs::conv_up_phase4}, {"pp_sched", &AfKnobs::pp_sched},
-      {"attn_short", &AfKnobs::attn_short}, {"rowpanel_deep", &AfKnobs::rowpanel_deep},
-      {"gemm_m128", &AfKnobs::gemm_m128}, {"small_m_tile64", &AfKnobs::small_m_tile64}, {"gn_reduce", &AfKnobs::gn_reduce}, {"gn_consumer", &AfKnobs::gn_consumer}, {"splitk_inlaunch", &AfKnobs::splitk_inlaunch}, {"plan_log", &AfKnobs::plan_log}};
+      {"attn_short", &AfKnobs::attn_short},
+      {"gemm_m128", &AfKnobs::gemm_m128}, {"small_m_tile64", &AfKnobs::small_m_tile64}, {"gn_consumer", &AfKnobs::gn_consumer}, {"plan_log", &AfKnobs::plan_log}};
   if (!name) return nullptr;
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) return &(g_af_knobs.*(t.m));
@@ -79,8 +79,8 @@ static int* knob_slot(const char* name) {
 // ----------------------------------------------------------------------------
 int g_af_prof_enabled = 0;
 int g_af_prof_stride = 1;
-long g_af_prof_seen[AF_K_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-double g_af_flops_issued = 0.0;
+std::atomic<long> g_af_prof_seen[AF_K_COUNT] = {};
+std::atomic<double> g_af_flops_issued{0.0};
 namespace {
 struct ProfRec {
   hipEvent_t start, stop;
@@ -152,13 +152,6 @@ struct Act {  // NHWC activation view
   // gn_stats_out); valid for exactly the B samples and C channels of this view
   const float* gn_part = nullptr;
   int gn_npart = 0;
-  // the tensor exists only as the fp32 split-K slabs of the convolution that produces it (ConvGemmParams::defer_reduce): the
-  // one consumer, a single-launch GroupNorm, sums them (slab_k slices of [npix][C], + bias, + per-sample row bias)
-  const float* slabs = nullptr;
-  int slab_k = 0;
-  const float* slab_bias = nullptr;
-  const void* slab_rowbias = nullptr;
-  int slab_ldrb = 0;
   long npix() const { return (long)B * H * W; }
 };
 
@@ -854,13 +847,9 @@ struct Runner {
     ConvGemmParams p;
     conv_params(p, L, x, out, 1, 0, nullptr, nullptr, 0, n_valid, -1);
     const AfGemmPlan pl = af_plan_conv_gemm(p, 1, (int)esize(dt));
-    {   // the 128 x 160 tile GEMM (16x16 level) carries both epilogues, in the tiled kernel's slab layout (80 columns per slab)
-      ConvGemmParams q = p;
-      q.splitk = 1;
-      // (ln_fuse = 3 only: at the 16x16 level the fold measures neutral, 15.834 vs 15.842 ms per forward -- a stand-alone
-      // LayerNorm over [4096, 1280] costs what the two epilogues and the statistics traffic cost)
-      if (g_af_knobs.ln_fuse == 3 && af_conv_rowpanel_kind(q, 1) == 6) return (p.N / 160) * 2;
-    }
+    // (folding at the 16x16 level through the 128 x 160 tile GEMM's epilogues measured neutral in round 3 -- 15.834 vs 15.842 ms per
+    // forward: a stand-alone LayerNorm over [4096, 1280] costs what the two epilogues and the statistics traffic cost -- and is not
+    // planned; at the 32x32 level the same kernel's two-slot form carries the epilogues)
     if (pl.tile < 4 || pl.splitk > 1 || pl.halo_tw) return 0;
     return (p.N / (pl.tile == 5 ? 160 : 128)) * 2;
   }
@@ -889,13 +878,10 @@ struct Runner {
   }
   // want_gn: 1 = also write the GroupNorm partial sums of `out` into the arena (consumer inside the caller's arena scope),
   // 2 = into the handle's carry buffer (consumer = the next layer); out.gn_part is set when the launch can do it
-  // defer_ok: the caller's ONLY consumer of `out` is a GroupNorm that af_gn_small_ok says runs as the single-launch kernel: a
-  // launch that slices K then leaves its slabs un-reduced (out.slabs) and `out`'s buffer is never written
   int conv(const Linear& L, const Act& x, Act& out, int stride, int up, const Act* residual, const void* rowbias,
-           int ldrb, int n_valid = -1, int pad = -1, const LnArgs* ln = nullptr, int want_gn = 0, bool defer_ok = false) {
+           int ldrb, int n_valid = -1, int pad = -1, const LnArgs* ln = nullptr, int want_gn = 0) {
     AF_TRY(check(out));
     out.gn_part = nullptr; out.gn_npart = 0;
-    out.slabs = nullptr; out.slab_k = 0;
     ConvGemmParams p;
     conv_params(p, L, x, out, stride, up, residual, rowbias, ldrb, n_valid, pad);
     bool ln_parts_pending = false;
@@ -955,20 +941,10 @@ struct Runner {
     }
     void* ws = nullptr;
     if (pl.splitk > 1) {
-      const bool defer = defer_ok && g_af_knobs.gn_reduce && !x.f8 && !residual && !ln && out.C == p.N && L.ks * L.ks * L.cin_pad == p.K &&
-                         af_gn_small_ok(out.H * out.W, out.C, (int)esize(dt));
       const size_t mk = A.mark();
       ws = A.alloc(pl.ws_bytes);  // consumed by the reduce kernel enqueued in this call; later allocations
-      if (!defer) A.release(mk);  // are only touched by later (stream-ordered) kernels -- unless the consumer reduces:
-      if (!ws) { af_set_error_msg("arena exhausted (split-K slabs)"); return AF_ERR_STATE; }   // then they live on in the caller's scope
-      if (defer) {
-        p.defer_reduce = 1;
-        out.slabs = reinterpret_cast<const float*>(ws);
-        out.slab_k = pl.splitk;
-        out.slab_bias = p.bias;
-        out.slab_rowbias = p.rowbias;
-        out.slab_ldrb = p.ldrb;
-      }
+      A.release(mk);              // are only touched by later (stream-ordered) kernels
+      if (!ws) { af_set_error_msg("arena exhausted (split-K slabs)"); return AF_ERR_STATE; }
     }
     if (dry) return 0;
     return DISPATCH(dt, af_launch_conv_gemm<bf16>(p, 1, s, &pl, ws), af_launch_conv_gemm<float>(p, 1, s, &pl, ws));
@@ -984,17 +960,6 @@ struct Runner {
     if (!ws) { af_set_error_msg("arena exhausted (groupnorm workspace)"); return AF_ERR_STATE; }
     if (dry) return 0;
     if (x.C != N.C) { af_set_error_msg("groupnorm: C mismatch %d vs %d", x.C, N.C); return AF_ERR_INVALID; }
-    if (x.slabs) {   // x was never materialised: reduce its producer's split-K slabs on the way in
-      const float f8 = y.f8 ? (float)(1 << AF_FP8_ACT_SHIFT) : 0.f;
-      if (y.f8)
-        return af_launch_groupnorm_slabs<bf16>(x.slabs, x.slab_k, (int)x.npix(), x.C, x.slab_bias, x.slab_rowbias, x.slab_ldrb, x.B, HW,
-                                               x.C, N.gamma, N.beta, N.eps, silu, y.p, (long)HW * y.ld, y.ld, s, f8);
-      return DISPATCH(dt,
-                      af_launch_groupnorm_slabs<bf16>(x.slabs, x.slab_k, (int)x.npix(), x.C, x.slab_bias, x.slab_rowbias, x.slab_ldrb, x.B,
-                                                      HW, x.C, N.gamma, N.beta, N.eps, silu, y.p, (long)HW * y.ld, y.ld, s, 0.f),
-                      af_launch_groupnorm_slabs<float>(x.slabs, x.slab_k, (int)x.npix(), x.C, x.slab_bias, x.slab_rowbias, x.slab_ldrb, x.B,
-                                                       HW, x.C, N.gamma, N.beta, N.eps, silu, y.p, (long)HW * y.ld, y.ld, s, 0.f));
-    }
     // (statistics already summed by the convolution that produced x: no pass over the tensor for them)
     const float* pre = g_af_knobs.gn_producer ? x.gn_part : nullptr;
     if (y.f8)
@@ -1050,9 +1015,7 @@ static int run_resblock(Runner& R, const ResBlockW& w, const Act& x, Act& out, c
   AF_TRY(R.groupnorm(w.n1, x, t1, 1));
   const void* rb = (emb_all && w.emb_off >= 0) ? R.elem_ptr(const_cast<void*>(emb_all), w.emb_off) : nullptr;
   // (conv1 also sums the GroupNorm statistics of its output where its kernel can: n2 then makes no pass for them)
-  // (... and where it slices K and n2 is the single-launch small-map kernel, n2 reduces the slabs itself: t2 is then never
-  // written -- its only reader is n2)
-  AF_TRY(R.conv(w.c1, t1, t2, 1, 0, nullptr, rb, emb_ld, -1, -1, nullptr, 1, true));
+  AF_TRY(R.conv(w.c1, t1, t2, 1, 0, nullptr, rb, emb_ld, -1, -1, nullptr, 1));
   Act t3 = R.fp8_capable(w.c2, t2, out) ? R.alloc_act8(x.B, x.H, x.W, w.cout) : R.alloc_act(x.B, x.H, x.W, w.cout);
   AF_TRY(R.groupnorm(w.n2, t2, t3, 1));
   Act sk = x;
@@ -2287,8 +2250,7 @@ int af_prof_reset(void) {
   return 0;
 }
 double af_flops_issued(int reset) {
-  const double v = g_af_flops_issued;
-  if (reset) g_af_flops_issued = 0.0;
+  const double v = reset ? g_af_flops_issued.exchange(0.0) : g_af_flops_issued.load();
   return v;
 }
 int af_prof_set_stride(int every) {
@@ -2297,9 +2259,10 @@ int af_prof_set_stride(int every) {
   return AF_OK;
 }
 int af_last_gemm_plan(int* tile, int* splitk, int* halo_tw) {
-  if (tile) *tile = g_af_last_plan.tile;
-  if (splitk) *splitk = g_af_last_plan.splitk;
-  if (halo_tw) *halo_tw = g_af_last_plan.halo_tw;
+  const AfGemmPlan lp = af_get_last_plan();
+  if (tile) *tile = lp.tile;
+  if (splitk) *splitk = lp.splitk;
+  if (halo_tw) *halo_tw = lp.halo_tw;
   return AF_OK;
 }
 int af_gemm_plan_counts(int64_t* counts10) {
@@ -2310,8 +2273,6 @@ int af_gemm_plan_counts(int64_t* counts10) {
 int af_gemm_plan_counts_reset(void) {
   g_af_attn_short_launches = 0;
   g_af_gn_consumer_launches = 0;
-  g_af_deferred_reduces = 0;
-  g_af_inlaunch_reduces = 0;
   for (int i = 0; i < 15; ++i) g_af_plan_counts[i] = 0;
   return AF_OK;
 }
@@ -2322,9 +2283,6 @@ int64_t af_up_phase4_launches(void) { return g_af_plan_counts[13]; }
 int64_t af_gn_producer_launches(void) { return g_af_plan_counts[14]; }
 int64_t af_attn_short_launches(void) { return g_af_attn_short_launches; }
 int64_t af_gn_consumer_launches(void) { return g_af_gn_consumer_launches; }
-int64_t af_deferred_reduces(void) { return g_af_deferred_reduces; }
-int64_t af_inlaunch_reduces(void) { return g_af_inlaunch_reduces; }
-int64_t af_inlaunch_reduce_timeouts(void) { return af_sk_timeouts_total(); }
 int af_set_fp8(af_handle* h, int on) {
   if (!h) { af_set_error_msg("af_set_fp8: null handle"); return AF_ERR_INVALID; }
   if (on && h->dtype != AF_DTYPE_BF16) { af_set_error_msg("af_set_fp8: the fp8 convolutions extend the bf16 mode (handle is f32)"); return AF_ERR_STATE; }

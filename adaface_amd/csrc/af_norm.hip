@@ -316,23 +316,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 // ~7-9 us each, both launch-latency bound at these sizes).  Sums in fp32 per lane, wave shuffles, the four wave
 // partials combined in fp64 in a fixed order (bitwise reproducible).
 #define GNS_MAXV 10
-// SLABS = true (round 3): x does not exist yet -- it is the output of a convolution that sliced K and left its fp32 partial
-// slabs ws[z][M][N] un-reduced (ConvGemmParams::defer_reduce).  The kernel forms each vector exactly as splitk_reduce_kernel
-// would have stored it (slabs summed in slice order, + bias, + the per-sample time-embedding row, one rounding to T) and
-// normalises that: the reduce launch and the read of its output are gone (ResBlock conv1 -> GroupNorm on 8x8 / 16x16 maps).
-struct GnSlabSrc {
-  const float* ws;        // [splitk][M][N]
-  int splitk, M, N;
-  const float* bias;      // [N] or null
-  const void* rowbias;    // T [B][ldrb] or null
-  int ldrb;
-};
-template <typename T, bool SLABS = false>
+template <typename T>
 __global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x, long batch_stride, int ldc, int HW,
                                                         int Cn, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int silu,
-                                                        T* __restrict__ y, long y_batch_stride, int ldy, float fp8_mul,
-                                                        GnSlabSrc src = GnSlabSrc{nullptr, 0, 0, 0, nullptr, nullptr, 0}) {
+                                                        T* __restrict__ y, long y_batch_stride, int ldy, float fp8_mul) {
   constexpr int EPC = 16 / sizeof(T);
   __shared__ float s_ra[4], s_rq[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -349,44 +337,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x, 
     const int it = tid + i * 256;
     if (it < nitems) {
       const int pix = it / VP, vv = it - pix * VP;
-      if constexpr (SLABS) {
-        const long m = (long)b * HW + pix;
-        const int n = g * cpg + vv * EPC;
-        float acc[EPC];
-#pragma unroll
-        for (int t = 0; t < EPC / 4; ++t) {
-          // slices in groups of eight: all loads of a group are issued before the first add (same summation order)
-          const float* base = src.ws + m * src.N + n + 4 * t;
-          const long zs = (long)src.M * src.N;
-          float4 s4 = float4{0.f, 0.f, 0.f, 0.f};
-          for (int z0 = 0; z0 < src.splitk; z0 += 8) {
-            float4 part[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-              part[u] = z0 + u < src.splitk ? *reinterpret_cast<const float4*>(base + (z0 + u) * zs) : float4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              if (z0 + u == 0) s4 = part[0];
-              else if (z0 + u < src.splitk) { s4.x += part[u].x; s4.y += part[u].y; s4.z += part[u].z; s4.w += part[u].w; }
-            }
-          }
-          acc[4 * t] = s4.x; acc[4 * t + 1] = s4.y; acc[4 * t + 2] = s4.z; acc[4 * t + 3] = s4.w;
-          if (src.bias) {
-            const float4 bv = *reinterpret_cast<const float4*>(src.bias + n + 4 * t);
-            acc[4 * t] += bv.x; acc[4 * t + 1] += bv.y; acc[4 * t + 2] += bv.z; acc[4 * t + 3] += bv.w;
-          }
-          if (src.rowbias) {
-            Quad<T> rb;
-            rb.load(reinterpret_cast<const T*>(src.rowbias) + (long)b * src.ldrb + n + 4 * t);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[4 * t + e] += to_f32<T>(rb.e[e]);
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) v[i].e[e] = from_f32<T>(acc[e]);
-      } else {
-        v[i].u = *reinterpret_cast<const uint4*>(xb + (long)pix * ldc + vv * EPC);
-      }
+      v[i].u = *reinterpret_cast<const uint4*>(xb + (long)pix * ldc + vv * EPC);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
         const float f = to_f32<T>(v[i].e[e]);
@@ -533,30 +484,6 @@ size_t af_gn_workspace_bytes(int B, int HW) {
   return ((size_t)B * nchunk * GN_GROUPS * 2 + (size_t)B * GN_GROUPS * 2) * sizeof(float);
 }
 
-// does GroupNorm on this shape run as the single-launch register-resident kernel (the only consumer of un-reduced slabs)?
-bool af_gn_small_ok(int HW, int Cn, int elem_size) {
-  const int EPC = 16 / elem_size, cpg = Cn / GN_GROUPS;
-  return g_af_knobs.gn_small != 0 && Cn % GN_GROUPS == 0 && cpg % EPC == 0 && (long)HW * (cpg / EPC) <= 256 * GNS_MAXV && Cn % 4 == 0 &&
-         Cn <= GN_MAX_C;
-}
-// GroupNorm (+SiLU) of a convolution output that exists only as fp32 split-K slabs (see gn_small_kernel<T, true>)
-template <typename T>
-int af_launch_groupnorm_slabs(const float* ws, int splitk, int M, int N, const float* bias, const void* rowbias, int ldrb, int B,
-                              int HW, int Cn, const float* gamma, const float* beta, float eps, int silu, void* y, long y_bs,
-                              int ldy, hipStream_t stream, float fp8_mul) {
-  if (!af_gn_small_ok(HW, Cn, (int)sizeof(T)) || N != Cn || M != B * HW || splitk < 2 || (rowbias && ldrb % 4 != 0)) {
-    af_set_error_msg("groupnorm over split-K slabs: shape B=%d HW=%d C=%d N=%d has no single-launch kernel", B, HW, Cn, N);
-    return -1;
-  }
-  if (fp8_mul != 0.f && sizeof(T) != 2) { af_set_error_msg("groupnorm: fp8 output needs the bf16 storage mode"); return -1; }
-  AfProfScope prof(AF_K_GROUPNORM, stream, 0.0, (double)B * HW * Cn * (4.0 * splitk + sizeof(T)));
-  GnSlabSrc src{ws, splitk, M, N, bias, rowbias, ldrb};
-  hipLaunchKernelGGL((gn_small_kernel<T, true>), dim3(GN_GROUPS, B), dim3(256), 0, stream, (const T*)nullptr, 0L, 0, HW, Cn, gamma,
-                     beta, eps, silu, reinterpret_cast<T*>(y), y_bs, ldy, fp8_mul, src);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
-}
-
 template <typename T>
 int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn, const float* gamma,
                         const float* beta, float eps, int silu, void* y, long y_bs, int ldy, void* workspace,
@@ -573,9 +500,8 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
     const int cpg = Cn / GN_GROUPS;
     const bool small_ok = g_af_knobs.gn_small != 0;
     if (small_ok && cpg % EPC == 0 && (long)HW * (cpg / EPC) <= 256 * GNS_MAXV && Cn % 4 == 0) {
-      hipLaunchKernelGGL((gn_small_kernel<T, false>), dim3(GN_GROUPS, B), dim3(256), 0, stream, reinterpret_cast<const T*>(x),
-                         x_bs, ldx, HW, Cn, gamma, beta, eps, silu, reinterpret_cast<T*>(y), y_bs, ldy, fp8_mul,
-                         GnSlabSrc{nullptr, 0, 0, 0, nullptr, nullptr, 0});
+      hipLaunchKernelGGL((gn_small_kernel<T>), dim3(GN_GROUPS, B), dim3(256), 0, stream, reinterpret_cast<const T*>(x),
+                         x_bs, ldx, HW, Cn, gamma, beta, eps, silu, reinterpret_cast<T*>(y), y_bs, ldy, fp8_mul);
       HIP_CHECK_RET(hipGetLastError());
       return 0;
     }
@@ -595,8 +521,7 @@ int af_launch_groupnorm(const void* x, long x_bs, int ldx, int B, int HW, int Cn
                        reinterpret_cast<const T*>(x), x_bs, ldx, HW, Cn, P, reinterpret_cast<float*>(workspace), nchunk);
   }
   const double count = (double)HW * (double)(Cn / GN_GROUPS);
-  const bool fold_ok = g_af_knobs.gn_fold != 0;
-  const bool fold = fold_ok && npart <= 64;  // few chunks: the apply blocks finalize the statistics themselves
+  const bool fold = npart <= 64;  // few chunks: the apply blocks finalize the statistics themselves
   if (!fold) hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, partial, npart, count, eps, stats);
   hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nchunk, B), dim3(256), 0, stream,
                      reinterpret_cast<const T*>(x), x_bs, ldx, HW, Cn, P, stats, gamma, beta, silu,
@@ -702,10 +627,6 @@ template int af_launch_groupnorm<bf16>(const void*, long, int, int, int, int, co
                                        int, void*, long, int, void*, hipStream_t, float, const float*, int);
 template int af_launch_groupnorm<float>(const void*, long, int, int, int, int, const float*, const float*, float,
                                         int, void*, long, int, void*, hipStream_t, float, const float*, int);
-template int af_launch_groupnorm_slabs<bf16>(const float*, int, int, int, const float*, const void*, int, int, int, int, const float*,
-                                             const float*, float, int, void*, long, int, hipStream_t, float);
-template int af_launch_groupnorm_slabs<float>(const float*, int, int, int, const float*, const void*, int, int, int, int, const float*,
-                                              const float*, float, int, void*, long, int, hipStream_t, float);
 template int af_launch_groupnorm_fold<bf16>(const void*, long, int, int, int, int, const float*, const float*, float, void*,
                                             hipStream_t, const float*, int, float*);
 template int af_launch_groupnorm_fold<float>(const void*, long, int, int, int, int, const float*, const float*, float, void*,

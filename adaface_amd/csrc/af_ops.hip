@@ -92,9 +92,13 @@ int af_clock_probe(void* stream, int iters, double* mfma_mhz, double* mfma_tflop
   Tmp tmp;
   OP_ALLOC(stamps, (size_t)blocks * 4 * 2 * sizeof(unsigned long long), true);
   OP_ALLOC(sink, (size_t)blocks * 256 * sizeof(float), false);
-  hipEvent_t e0, e1;
-  HIP_CHECK_RET(hipEventCreate(&e0));
-  HIP_CHECK_RET(hipEventCreate(&e1));
+  struct Ev {   // destroyed on every exit path
+    hipEvent_t e = nullptr;
+    ~Ev() { if (e) hipEventDestroy(e); }
+  } ev0, ev1;
+  HIP_CHECK_RET(hipEventCreate(&ev0.e));
+  HIP_CHECK_RET(hipEventCreate(&ev1.e));
+  hipEvent_t e0 = ev0.e, e1 = ev1.e;
   // one short launch to wake the device, then the timed one
   hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, s, (unsigned long long*)stamps, (float*)sink, 2000);
   HIP_CHECK_RET(hipEventRecord(e0, s));
@@ -103,8 +107,6 @@ int af_clock_probe(void* stream, int iters, double* mfma_mhz, double* mfma_tflop
   HIP_CHECK_RET(hipEventSynchronize(e1));
   float ms = 0.f;
   HIP_CHECK_RET(hipEventElapsedTime(&ms, e0, e1));
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
   std::vector<unsigned long long> h((size_t)blocks * 8);
   HIP_CHECK_RET(hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   std::vector<double> mhz;

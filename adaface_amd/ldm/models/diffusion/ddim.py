@@ -151,8 +151,6 @@ class DDIMSampler(object):
                       guidance_scale=1., unconditional_conditioning=None):
         """ddim.py:222-296."""
         b, device = x.shape[0], x.device
-        if quantize_denoised or score_corrector is not None:
-            raise NotImplementedError("quantize_denoised / score_corrector are not on the txt2img path")
         if unconditional_conditioning is None or guidance_scale == 1.:
             e_c, e_u = self.model.apply_model(x, t, c), None
         else:
@@ -178,8 +176,23 @@ class DDIMSampler(object):
             noise = torch.nn.functional.dropout(noise, p=noise_dropout)
         if sigma_t == 0.:
             noise = None
+        if score_corrector is not None:
+            # ddim.py:262-264: the corrector sees the COMBINED score; combine first (af_lincomb, the kernel's own CFG form),
+            # then hand its result to the update as a plain eps
+            assert self.model.parameterization == "eps"
+            e_t = e_c if e_u is None else ops.lincomb([(e_c, guidance_scale), (e_u, 0.0)], cfg=True)
+            e_c, e_u = score_corrector.modify_score(self.model, e_t, x, t, c, **(corrector_kwargs or {})), None
         x_prev, pred_x0 = ops.ddim_step(x, e_c, e_u, guidance_scale, f32(alphas[index]), f32(alphas_prev[index]),
                                         f32(sqrt_one_minus_alphas[index]), sigma_t, noise, temperature)
+        if quantize_denoised:
+            # ddim.py:281-282,293: x_prev is rebuilt around the quantised pred_x0 (a VQ first stage; AutoencoderKL has no
+            # `quantize`, and the reference raises AttributeError there as this does).  x_prev - sqrt(a_prev) pred_x0 is the
+            # dir_xt + noise term the fused kernel already formed, so only the pred_x0 term is swapped (fp32 scalars as the
+            # reference's torch.full(...) materialises them)
+            q, _, *_ = self.model.first_stage_model.quantize(pred_x0)
+            sa = float(np.sqrt(np.float32(f32(alphas_prev[index]))))
+            x_prev = ops.lincomb([(x_prev, 1.0), (pred_x0, -sa), (q, sa)])
+            pred_x0 = q
         return x_prev, pred_x0
 
     @torch.no_grad()

@@ -12,7 +12,9 @@
  *     the library never frees or retains them past the call (stream-ordered)
  *   - tensors crossing the boundary use the REFERENCE's layout and dtype
  *     (NCHW float32, int64 timesteps); NHWC bf16/f32 is internal
- *   - `stream` is a hipStream_t (0 = default stream); a handle is not thread-safe
+ *   - `stream` is a hipStream_t (0 = default stream); a HANDLE is not thread-safe (one host thread at a time per handle), but
+ *     distinct handles may be driven from distinct host threads: the library's process-wide state (launch counters, the
+ *     per-kernel LDS attribute masks, the last plan) is atomic / locked; the counters then count all threads' launches
  */
 #ifndef ADAFACE_HIP_H
 #define ADAFACE_HIP_H
@@ -203,8 +205,11 @@ int af_gemm_plan_counts_reset(void);
  * AF_* environment variables when the library is loaded (AF_GEMM_PP_MINFILL -> "gemm_pp_minfill", ...); nothing on the
  * launch path reads the environment.  The parity tests use af_knob_set to reach a kernel variant regardless of the
  * planner's choice and af_knob_reset to restore the load-time values.  No knob changes results beyond the summation
- * order of the chosen tiling.  Names: splitk_target, conv_halo, gemm_pp, gemm_pp_geglu_minkt, gemm_pp_minfill,
- * gemm_tile, gemm_splitk, gemm_groupm, gemm_dma, pp_direct, attn_w4, attn_ring, gn_small, gn_fold, conv_tap_inner, ln_fuse. */
+ * order of the chosen tiling.  The 26 names (adaface_amd/csrc/af_common.h, struct AfKnobs): splitk_target, conv_halo, gemm_pp,
+ * gemm_pp_geglu_minkt, gemm_pp_minfill, gemm_tile, gemm_splitk, gemm_groupm, gemm_dma, pp_direct, attn_ring, gn_small,
+ * conv_tap_inner, ln_fuse, geglu_rowpanel, conv_halo8, conv_fast_taps, pp_stagger, gn_producer, conv_up_phase4, pp_sched,
+ * attn_short, gemm_m128, small_m_tile64, gn_consumer, plan_log.  Round 4 removed the five that selected a measured-neutral or
+ * slower variant (gn_reduce, splitk_inlaunch, rowpanel_deep, gn_fold, attn_w4; numbers in DESIGN.md section 5). */
 int af_knob_set(const char* name, int value);
 int af_knob_get(const char* name, int* value);
 int af_knob_reset(void);
@@ -244,14 +249,6 @@ int64_t af_gn_producer_launches(void); /* convolutions that also wrote the Group
 int64_t af_attn_short_launches(void);
 /* row-panel GEMM launches that applied the GroupNorm of their input in their prologue (SpatialTransformer.norm + proj_in) */
 int64_t af_gn_consumer_launches(void);
-/* sliced-K convolutions whose fp32 slabs were reduced by the single-launch GroupNorm that consumes them (no reduce launch) */
-int64_t af_deferred_reduces(void);
-/* sliced-K launches that reduced their fp32 slabs themselves (the slices of a tile meet on a counter and each finishes a share
- * of its rows; only when the whole grid is resident at once) -- no splitk_reduce launch */
-int64_t af_inlaunch_reduces(void);
-/* waits of that reduction that gave up (a slice never arrived within ~0.5 s; the launch's outputs are then wrong), summed over
- * the process's streams.  Synchronises the device.  0 in every test, smoke() and bench.py run. */
-int64_t af_inlaunch_reduce_timeouts(void);
 int64_t af_up_phase4_launches(void); /* upsampled 3x3 convolutions run as four 2x2 phase convolutions on the stored map */
 int64_t af_rowpanel_launches(void); /* launches of the row-panel kernels (K = 320 / 640 / 1280 GEMMs with the activation rows resident in registers) */
 int af_op_conv2d_fp8(const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev, float* y_dev,

@@ -603,12 +603,15 @@ def q_sample(schedule: dict, x_start: Tensor, t: Tensor, noise: Tensor) -> Tenso
 def ddim_sample(apply_model: Callable[[Tensor, Tensor, Tensor], Tensor], schedule: dict, S: int, x_T: Tensor,
                 cond: Tensor, uncond: Tensor, guidance_scale=(10.0, 4.0), eta: float = 0.0,
                 return_trajectory: bool = False, mask: Optional[Tensor] = None, x0: Optional[Tensor] = None,
-                q_noise: Optional[Tensor] = None):
+                q_noise: Optional[Tensor] = None, score_corrector: Optional[Callable[[Tensor, Tensor, Tensor], Tensor]] = None,
+                quantize: Optional[Callable[[Tensor], Tensor]] = None):
     """DDIMSampler.sample/ddim_sampling/p_sample_ddim (ddim.py:71-296) for eta = 0:
     one batched model call on cat[x,x], cat[t,t], cat[cond, uncond] (cond FIRST, :243), CFG combine (:260),
     per-step scalars cast to fp32 through torch.full (:273-276), x_{t-1} update (:279-295), annealed
     guidance (:169-180,215-218).  apply_model(x [2B,..], t [2B], ctx [2B*L,T,D]) -> eps [2B,..].
-    mask / x0 / q_noise: the inpainting blend in front of every step (:190-195)."""
+    mask / x0 / q_noise: the inpainting blend in front of every step (:190-195).
+    score_corrector(e_t, x, t) -> e_t: applied to the COMBINED score (:262-264); quantize(pred_x0) -> pred_x0: replaces the x_0
+    prediction before x_{t-1} is formed (:281-282, quantize_denoised)."""
     ts = make_ddim_timesteps(S, schedule["alphas_cumprod"].shape[0])
     sigmas, alphas, alphas_prev = make_ddim_sampling_parameters(schedule["alphas_cumprod"], ts, eta)
     sqrt_one_minus = np.sqrt(1.0 - alphas)
@@ -624,11 +627,15 @@ def ddim_sample(apply_model: Callable[[Tensor, Tensor, Tensor], Tensor], schedul
             img = q_sample(schedule, x0, t, q_noise[i]) * mask + (1.0 - mask) * img
         e_c, e_u = apply_model(torch.cat([img] * 2), torch.cat([t] * 2), torch.cat([cond, uncond])).chunk(2)
         e_t = e_u + gs[i] * (e_c - e_u)
+        if score_corrector is not None:
+            e_t = score_corrector(e_t, img, t)
         a_t = torch.full((b, 1, 1, 1), alphas[index])
         a_prev = torch.full((b, 1, 1, 1), alphas_prev[index])
         sigma_t = torch.full((b, 1, 1, 1), sigmas[index])
         s1m = torch.full((b, 1, 1, 1), sqrt_one_minus[index])
         pred_x0 = (img - s1m * e_t) / a_t.sqrt()
+        if quantize is not None:
+            pred_x0 = quantize(pred_x0)
         dir_xt = (1.0 - a_prev - sigma_t ** 2).sqrt() * e_t
         img = a_prev.sqrt() * pred_x0 + dir_xt
         if return_trajectory:

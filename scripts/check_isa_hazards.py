@@ -12,6 +12,10 @@ documented case); the kernel was fixed by computing every offset first and issui
 Flagged: a VMEM store of 12 or 16 bytes whose data registers are written by a VALU instruction in one of the next
 `--slots` (default 2) instruction slots.  (Loads into the same registers are not flagged: their data comes back tens of cycles later.)
 
+What it does NOT cover: stores whose overwrite sits behind a taken branch; the lab builds under scripts/lab/ (not part of the
+library); any other unpadded hazard class.  The kernels with 16-byte SGPR-offset stores (gemm_m128_kernel, rowpanel_kernel) do
+not rely on it alone: their epilogues compute every offset first and issue the stores back to back behind a sched_barrier.
+
 Usage:  python scripts/check_isa_hazards.py            (after build(): reads adaface_amd/_build/*.o)
 Exit code 1 if anything is flagged.  tests/test_host_cpu.py runs scan() in the CPU suite.
 """
@@ -70,8 +74,10 @@ def scan_function(name: str, ins: list, slots: int):
             if i + k >= len(ins):
                 break
             u = ins[i + k]
-            if u.startswith(("s_nop", "s_waitcnt", "s_barrier", "s_endpgm", "s_branch", "s_cbranch")):
-                break                     # (wait states / control flow: past the window this scan can judge)
+            if u.startswith(("s_nop", "s_barrier", "s_endpgm", "s_branch", "s_cbranch", "s_setpc", "s_swappc")):
+                break                     # (s_nop N = N + 1 wait states, one is what the documented hazard asks for; control
+                                          # flow: past the window this scan can judge)
+            # (an s_waitcnt takes a slot but guarantees no wait state when its counters are already satisfied: scan on)
             if u.startswith("v_") and not u.startswith(("v_cmp", "v_nop")):
                 dst = u.split(None, 1)[1].split(",")[0]
                 if _regs(dst) & data:
@@ -84,6 +90,13 @@ def scan(slots: int = 2):
     objs = sorted((ROOT / "adaface_amd" / "_build").glob("*.o"))
     if not objs:
         raise RuntimeError("no objects under adaface_amd/_build: run __graft_entry__.build() first")
+    # the objects must be what the sources say: a stale object would be scanned in place of the code that ships
+    csrc = ROOT / "adaface_amd" / "csrc"
+    newest_h = max(h.stat().st_mtime for h in list(csrc.glob("*.h")) + [ROOT / "include" / "adaface_hip.h"])
+    for obj in objs:
+        src = csrc / obj.name[:-2]
+        if src.exists() and obj.stat().st_mtime < max(src.stat().st_mtime, newest_h):
+            raise RuntimeError(f"{obj.name} is older than its sources: rebuild (python -m adaface_amd.build) before scanning")
     stores, hits = 0, []
     with tempfile.TemporaryDirectory() as td:
         for obj in objs:

@@ -339,6 +339,24 @@ def main():
     golden["inpaint_S5_samples"] = inp.numpy()
     assert len(drawn) == 5 and (inp - samples).abs().max() > 1e-2
 
+    # ---- round 4: the score_corrector and quantize_denoised branches of p_sample_ddim (ddim.py:262-264, 281-282).  The
+    # corrector and the quantiser are the TEST's (the reference ships neither on this path): modify_score(model, e_t, x, t, c,
+    # scale=, mix=) = scale * e_t + mix * x; first_stage_model.quantize(z) = (round(4 z) / 4, None, None).  What is pinned is
+    # where the reference sampler calls them and what it does with their results. ----
+    class Corr:
+        def modify_score(self, model_, e_t, x_, t_, c_, scale=1.0, mix=0.0):
+            return scale * e_t + mix * x_
+    model.parameterization = "eps"
+    model.first_stage_model = types.SimpleNamespace(quantize=lambda z: (torch.round(z * 4.0) / 4.0, None, None))
+    model.q_sample = None
+    kw = dict(conditioning=(c, ["p"] * B, extra_info()), batch_size=B, shape=[4, H, H], verbose=False,
+              guidance_scale=[7.0, 3.0], unconditional_conditioning=(uc, [""] * B, extra_info()), eta=0.0, x_T=x_T)
+    corr_s, _ = sampler.sample(S=5, score_corrector=Corr(), corrector_kwargs=dict(scale=0.9, mix=0.05), **kw)
+    quant_s, _ = sampler.sample(S=5, quantize_x0=True, **kw)
+    both_s, _ = sampler.sample(S=5, quantize_x0=True, score_corrector=Corr(), corrector_kwargs=dict(scale=0.9, mix=0.05), **kw)
+    golden["corr_S5_samples"], golden["quant_S5_samples"], golden["corrquant_S5_samples"] = corr_s.numpy(), quant_s.numpy(), both_s.numpy()
+    assert (corr_s - quant_s).abs().max() > 1e-2 and (both_s - quant_s).abs().max() > 1e-2
+
     np.savez_compressed(OUT / "golden_tiny.npz", **golden)
     print("wrote", OUT / "golden_tiny.npz", {k: v.shape for k, v in list(golden.items())[:6]}, "...")
 

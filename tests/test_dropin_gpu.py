@@ -181,6 +181,39 @@ def test_ddim_sampler_inpainting_matches_reference_sampler(gpu, report, tiny_mod
     assert calls == [801, 601, 401, 201, 1] and err < 1e-3, (calls, err)
 
 
+def test_ddim_sampler_score_corrector_and_quantize_match_reference_sampler(gpu, report, tiny_model):
+    """The score_corrector (ddim.py:262-264) and quantize_denoised (:281-282) branches of p_sample_ddim through the drop-in
+    sampler, against the REFERENCE sampler run with the same corrector (0.9 e_t + 0.05 x) and quantiser (round(4 z) / 4)."""
+    import types
+    from ldm.models.diffusion.ddim import DDIMSampler
+    g = dict(np.load(GOLD / "golden_tiny.npz"))
+    c = tiny_model.get_learned_conditioning(torch.tensor(g["ddim_c"], device=gpu))
+    uc = tiny_model.get_learned_conditioning(torch.tensor(g["ddim_uc"], device=gpu))
+
+    class Corr:
+        def modify_score(self, model_, e_t, x_, t_, c_, scale=1.0, mix=0.0):
+            return scale * e_t + mix * x_
+    # (instance attribute shadowing the registered sub-module for the duration of the test)
+    object.__setattr__(tiny_model, "first_stage_model", types.SimpleNamespace(quantize=lambda z: (torch.round(z * 4.0) / 4.0, None, None)))
+    try:
+        kw = dict(S=5, conditioning=c, batch_size=1, shape=[4, 16, 16], verbose=False, guidance_scale=[7.0, 3.0],
+                  unconditional_conditioning=uc, eta=0.0, x_T=torch.tensor(g["ddim_xT"], device=gpu))
+        ck = dict(score_corrector=Corr(), corrector_kwargs=dict(scale=0.9, mix=0.05))
+        for key, extra in (("corr_S5_samples", ck), ("quant_S5_samples", dict(quantize_x0=True)),
+                           ("corrquant_S5_samples", dict(quantize_x0=True, **ck))):
+            samples, _ = DDIMSampler(tiny_model).sample(**kw, **extra)
+            ref = g[key]
+            d = np.abs(samples.cpu().numpy() - ref)
+            # a quantiser is discontinuous: an element whose pred_x0 sits within rounding of a step may land on the other side
+            # (then it is off by a multiple of the step times sqrt(a_prev)); everything else is held to the sampler bar
+            frac_off = float((d > 1e-3 * np.abs(ref).max()).mean())
+            err = float(np.median(d) / np.abs(ref).max()) if "quant" in key else float(d.max() / np.abs(ref).max())
+            report(f"dropin DDIMSampler {key[:-11]} S=5 vs reference sampler [f32]", err, float(np.abs(ref).max()), 1e-3)
+            assert err < 1e-3 and frac_off < (2e-3 if "quant" in key else 1e-9), (key, err, frac_off)
+    finally:
+        object.__delattr__(tiny_model, "first_stage_model")
+
+
 def test_img2img_encode_decode_matches_reference_sampler(gpu, report, tiny_model):
     """DDIMSampler.stochastic_encode + .decode (ddim.py:299-350: the img2img tail, guidance annealed 5 -> 2 over the
     remaining steps) vs the reference sampler driving the reference UNet."""

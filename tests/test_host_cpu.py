@@ -48,7 +48,7 @@ def test_no_wide_store_is_followed_by_a_write_of_its_data_registers():
     import importlib.util
     from adaface_amd import _lib, build
     if not _lib.lib_path().exists() or not list((ROOT / "adaface_amd" / "_build").glob("*.o")):
-        build.build(verbose=False)
+        build.build(verbose=False)        # (a fresh tree only; objects OLDER than their sources make scan() raise, not rebuild)
     spec = importlib.util.spec_from_file_location("check_isa_hazards", ROOT / "scripts" / "check_isa_hazards.py")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
@@ -213,6 +213,13 @@ def test_bench_launches_its_own_ranks_gloo_world2():
     assert j2["n_gpus"] == 2 and j1["n_gpus"] == 1
     assert j2["config"]["global_batch"] == 8 and j2["scaling"] == "strong" and j2["value"] is None
     assert j2["checksum"] == j1["checksum"]            # results do not depend on the world size
+    assert j2["frames_sha256"] == j1["frames_sha256"]  # ... byte for byte: the rank-sharded, gathered frames ARE the world-1 frames
+    # per-rank view for reading a scaling curve: every rank's own wall time (min / max) and the all-gather's duration field
+    pr = j2["distributed"]["per_rank"]
+    assert set(pr) == {"dt_s_min", "dt_s_max", "all_gather_ms_per_step_mean", "all_gather_ms_per_step_max_over_ranks"}
+    assert 0 < pr["dt_s_min"] <= pr["dt_s_max"] and abs(pr["dt_s_max"] * 1e3 / 2 - j2["ms_per_step"]) < 1e-6
+    assert j2["distributed"]["world_size"] == 2 and j2["distributed"]["all_gather_calls"] == 3   # warm-up + 2 steps
+    assert "per_rank" in j1["distributed"]
     assert "PLUMBING TEST" in j2["metric"]
 
 

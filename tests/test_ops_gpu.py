@@ -288,14 +288,13 @@ def test_linear_m128_tile(gpu, report, knobs, M, K, N, bias, res):
         assert torch.equal(ops.linear(*args, dtype="bf16"), got)
 
 
-@pytest.mark.parametrize("B,C,H,W,N", [(8, 320, 64, 64, 320), (16, 640, 32, 32, 640), (9, 320, 64, 64, 960)])
+@pytest.mark.parametrize("B,C,H,W,N", [(8, 320, 64, 64, 320), (9, 320, 64, 64, 960)])
 def test_groupnorm_in_rowpanel_prologue(gpu, report, knobs, B, C, H, W, N):
     """SpatialTransformer.norm + proj_in with the GroupNorm applied in the row-panel GEMM's prologue (ConvGemmParams::gn_ab):
-    the rows it normalises in registers are bit for bit what gn_apply_kernel would have stored, so at K = 320 -- where the
-    un-fused launch runs on the same kernel -- the two outputs are IDENTICAL; at K = 640 the un-fused GEMM is the tiled
-    kernel (other summation order): bf16 bar.  Both against torch."""
+    the rows it normalises in registers are bit for bit what gn_apply_kernel would have stored, so -- the un-fused launch
+    running on the same kernel -- the two outputs are IDENTICAL.  Both against torch.  (The K = 640 form of round 3 measured
+    slower than the tiled kernel + the GroupNorm pass and left the product in round 4.)"""
     from adaface_amd import _lib, ops
-    knobs("gn_consumer", 2)          # (the K = 640 form is off by default: the tiled kernel is faster on the bare GEMM there)
     g = torch.Generator().manual_seed(B + C + N)
     x = _q(torch.randn(B, C, H, W, generator=g) * 1.3 + 0.5 * torch.randn(B, C, 1, 1, generator=g), "bf16")
     gamma = torch.randn(C, generator=g) * 0.2 + 1.0
@@ -367,57 +366,6 @@ def test_plain_rowpanel(gpu, report, knobs, M, K, N, bias, res):
     tiled = ops.linear(*args, dtype="bf16")
     assert _lib.plan_counts(reset=True)["rowpanel"] == 0
     assert torch.equal(got, tiled), (got - tiled).abs().max().item()
-
-
-@pytest.mark.parametrize("kind,shape", [
-    ("conv", (16, 1280, 16, 1280, 1, True)),     # halo kernel, 128 tiles x 2 K slices = 256 workgroups, residual
-    ("conv", (16, 2560, 16, 1280, 1, False)),    # ... 40 channel chunks
-    ("conv", (16, 1280, 8, 1280, 1, True)),      # gathering eight-wave kernel, 32 tiles x 8 slices
-    ("conv", (16, 2560, 8, 1280, 1, False)),
-    ("conv", (16, 1280, 16, 1280, 2, False)),    # stride 2 onto the 8x8 map
-    ("conv", (16, 640, 32, 640, 2, False)),      # stride 2, 64 tiles x 4 slices
-    ("conv", (16, 320, 64, 320, 2, False)),      # stride 2, 128 tiles x 2 slices
-    ("conv", (14, 1280, 8, 1280, 1, True)),      # 896 rows: a ragged last row tile (rows >= M are neither summed nor stored)
-    ("linear", (1024, 5120, 1280, True)),        # 5 slices: 256 rows do not divide (52-row shares, the last one shorter)
-    ("linear", (1000, 5120, 1280, False)),       # ... and a ragged last row tile
-])
-def test_splitk_reduced_in_launch(gpu, report, knobs, kind, shape):
-    """Sliced-K launches whose whole grid is resident at once reduce their fp32 slabs themselves (pp_inlaunch_reduce: the slices
-    of a tile meet on a counter, each finishes a share of the rows): bit-identical to the slabs + splitk_reduce_kernel path
-    (both go through splitk_reduce_quad), launch after launch (the counters return to zero), and no wait ever gives up."""
-    from adaface_amd import _lib, ops
-    knobs("splitk_inlaunch", 1)            # (default 0: measured no faster than the reduce launch it saves, DESIGN.md section 5)
-    g = torch.Generator().manual_seed(sum(int(v) for v in shape))
-    if kind == "conv":
-        B, Cin, H, Cout, stride, res = shape
-        x = _q(torch.randn(B, Cin, H, H, generator=g), "bf16").to(gpu)
-        w = _q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin), "bf16").to(gpu)
-        b = torch.randn(Cout, generator=g).to(gpu)
-        r = _q(torch.randn(B, Cout, H // stride, H // stride, generator=g), "bf16").to(gpu) if res else None
-        run = lambda: ops.conv2d(x, w, b, stride=stride, residual=r, dtype="bf16")
-        ref = F.conv2d(x, w, b, stride=stride, padding=1) + (r if res else 0)
-    else:
-        M, K, N, res = shape
-        x = _q(torch.randn(M, K, generator=g), "bf16").to(gpu)
-        w = _q(torch.randn(N, K, generator=g) / math.sqrt(K), "bf16").to(gpu)
-        b = torch.randn(N, generator=g).to(gpu)
-        r = _q(torch.randn(M, N, generator=g), "bf16").to(gpu) if res else None
-        run = lambda: ops.linear(x, w, b, r, dtype="bf16")
-        ref = F.linear(x, w, b) + (r if res else 0)
-    _lib.plan_counts(reset=True)
-    got = run()
-    pc = _lib.plan_counts(reset=True)
-    assert pc["splitk"] == 1 and pc["inlaunch_reduce"] == 1, pc
-    _cmp(report, f"in-launch split-K {kind} {shape}", got, ref, "bf16")
-    knobs("splitk_inlaunch", 0)
-    old = run()
-    pc0 = _lib.plan_counts(reset=True)
-    assert pc0["splitk"] == 1 and pc0["inlaunch_reduce"] == 0, pc0
-    assert torch.equal(got, old), (got - old).abs().max().item()
-    knobs("splitk_inlaunch", 1)
-    for _ in range(12):
-        assert torch.equal(run(), got)
-    assert _lib.load().af_inlaunch_reduce_timeouts() == 0
 
 
 @pytest.mark.parametrize("B,Cin,H,W,Cout,bias,res,splitk", [

@@ -194,6 +194,23 @@ def test_tiny_ddim_inpainting_matches_reference_sampler(tiny):
     assert np.abs(out.numpy() - ref).max() < 1e-5 * np.abs(ref).max()
 
 
+def test_tiny_ddim_score_corrector_and_quantize_match_reference_sampler(tiny):
+    """p_sample_ddim's score_corrector (ddim.py:262-264) and quantize_denoised (:281-282) branches: the reference sampler was
+    run with the generator's corrector (0.9 e_t + 0.05 x) and quantiser (round(4 z) / 4), alone and together."""
+    cfg = O.TINY_UNET
+    sd = O.synth_state_dict(O.unet_param_shapes(cfg), seed=11)
+    apply = lambda x, t, c: O.unet_forward(sd, cfg, x, t, c)
+    corr = lambda e, x, t: 0.9 * e + 0.05 * x
+    quant = lambda z: torch.round(z * 4.0) / 4.0
+    for key, kw in (("corr_S5_samples", dict(score_corrector=corr)), ("quant_S5_samples", dict(quantize=quant)),
+                    ("corrquant_S5_samples", dict(score_corrector=corr, quantize=quant))):
+        out = O.ddim_sample(apply, O.register_schedule(), 5, torch.tensor(tiny["ddim_xT"]), torch.tensor(tiny["ddim_c"]),
+                            torch.tensor(tiny["ddim_uc"]), guidance_scale=(7.0, 3.0), **kw)
+        ref = tiny[key]
+        # (a quantiser is discontinuous: an fp32 rounding difference that crosses a step moves that element by 1/4.  None does here.)
+        assert np.abs(out.numpy() - ref).max() < 1e-5 * np.abs(ref).max(), key
+
+
 def test_tiny_unet_compel_cfg_matches_reference(tiny):
     cfg = O.TINY_UNET
     sd = O.synth_state_dict(O.unet_param_shapes(cfg), seed=11)
