@@ -97,6 +97,8 @@ _SIGS = [
     ("af_gn_producer_launches", C.c_int64, []),
     ("af_attn_short_launches", C.c_int64, []),
     ("af_gn_consumer_launches", C.c_int64, []),
+    ("af_xattn_fused_launches", C.c_int64, []),
+    ("af_op_xattn_fused", C.c_int, [C.c_void_p] * 10 + [C.c_int] * 3 + [C.c_void_p]),
     ("af_op_conv2d_fp8", C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 10 + [_P]),
     ("af_op_groupnorm_fp8", C.c_int, [_P, _P, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("af_op_layernorm_fp8", C.c_int, [_P, _P, _P, C.c_float, _P, C.c_int64, C.c_int, C.c_int, _P]),
@@ -158,6 +160,7 @@ def plan_counts(reset: bool = False) -> dict:
     out["gn_producer"] = int(lib.af_gn_producer_launches())
     out["attn_short"] = int(lib.af_attn_short_launches())
     out["gn_consumer"] = int(lib.af_gn_consumer_launches())
+    out["xattn_fused"] = int(lib.af_xattn_fused_launches())
     if reset:
         lib.af_gemm_plan_counts_reset()
     return out

@@ -80,7 +80,6 @@ struct AfKnobs {
   int splitk_target;        // AF_SPLITK_TARGET        four-wave kernels: workgroups aimed for when slicing K
   int conv_halo;            // AF_CONV_HALO            0 = never use the LDS-halo 3x3 kernel
   int gemm_pp;              // AF_GEMM_PP              0 = never use the eight-wave ping-pong kernel
-  int gemm_pp_geglu_minkt;  // AF_GEMM_PP_GEGLU_MINKT  GEGLU on the ping-pong kernel from this many K tiles
   int gemm_pp_minfill;      // AF_GEMM_PP_MINFILL      ping-pong kernel from this grid fill (percent)
   int gemm_tile;            // AF_GEMM_TILE            >= 0: force a four-wave tile
   int gemm_splitk;          // AF_GEMM_SPLITK          >= 1: force the number of K slices
@@ -107,6 +106,8 @@ struct AfKnobs {
   int small_m_tile64;       // AF_SMALL_M_TILE64       0 = GEMMs with <= 1024 rows and K <= 2048 keep the cost model's tile / K slices
   int gn_consumer;          // AF_GN_CONSUMER          0 = the SpatialTransformer's GroupNorm always runs its own apply pass (never
                             //                         in the prologue of a row-panel proj_in, 64x64 level)
+  int xattn_fused;          // AF_XATTN_FUSED          0 = cross-attention of the 64x64-level transformers as three launches (to_q,
+                            //                         short-key attention, to_out + residual) instead of xattn_fused_kernel
   int plan_log;             // AF_PLAN_LOG             1 = one stderr line per GEMM / convolution launch: shape, tile, K slices (lab)
 };
 extern AfKnobs g_af_knobs;

@@ -2768,7 +2768,6 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
     // (GEGLU with few K tiles is bound by its epilogue -- ~6k VALU cycles of erf per SIMD against 7.5k cycles of main
     // loop at K = 320 -- which one workgroup per CU cannot overlap with another tile's MFMAs; with the register-phase
     // epilogue it still measures 10-18 % ahead of the four-wave kernel, so the threshold defaults to 0)
-    if (geglu && KT < g_af_knobs.gemm_pp_geglu_minkt) cand = -1;
     if (cand >= 0) {
       const int tbn = cand == 5 ? 160 : 128;
       const long nb = (long)((p.M + 255) / 256) * (p.N / tbn);

@@ -13,6 +13,24 @@ template <typename T> long af_attn_short_pack_elems(int B, int H, int dh, int Nk
 template <typename T>
 int af_launch_attn_short_pack(const void* v, int ldv, long bsv, int Nk, int H, int dh, int B, void* vt, hipStream_t stream);
 extern std::atomic<long> g_af_attn_short_launches;
+// ONE launch per cross-attention layer (bf16, C = 320, 8 heads x 40, <= 80 keys; af_xattn_fused.hip): LayerNorm-folded to_q,
+// attention over the packed context K / V, to_out + bias + residual, LayerNorm partial sums for the next consumer
+struct AfXattnFusedParams {
+  const void* x; int ldx; int M; int rows_per_sample;
+  const float* ln_stats; int ln_parts_n; float ln_inv_count, ln_eps;   // as ConvGemmParams::ln_stats / ln_parts_n
+  const void* wq; int ldwq; const float* q_colsum; const float* q_bias;
+  const void* kvpack;                                                  // af_launch_xattn_fused_pack
+  const void* wo; int ldwo; const float* o_bias;                       // K-permuted to_out weight (af_launch_xattn_fused_permute_wo)
+  void* out; int ldo;
+  float* ln_stats_out;                                                 // [4][M][2] or null
+  int Nk;
+};
+bool af_xattn_fused_ok(int M, int rows_per_sample, int C, int H, int dh, int Nk);
+long af_xattn_fused_pack_elems(int B, int H, int dh, int Nk);         // bf16 elements of the K / V pack of one layer (0 = no such kernel)
+int af_launch_xattn_fused_pack(const void* kv, int ldk, long bsk, int Nk, int B, float scale, void* pack, hipStream_t stream);
+int af_launch_xattn_fused_permute_wo(const void* w, int ldw, int rows, void* wp, int ldp, hipStream_t stream);
+int af_launch_xattn_fused(const AfXattnFusedParams& a, hipStream_t stream);
+extern std::atomic<long> g_af_xattn_fused_launches;
 
 size_t af_gn_workspace_bytes(int B, int HW);
 template <typename T>

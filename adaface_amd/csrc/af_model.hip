@@ -48,7 +48,7 @@ static int knob_env(const char* name, int dflt) {
 }
 AfKnobs g_af_knobs = {
     knob_env("AF_SPLITK_TARGET", 320), knob_env("AF_CONV_HALO", 1),       knob_env("AF_GEMM_PP", 1),
-    knob_env("AF_GEMM_PP_GEGLU_MINKT", 0), knob_env("AF_GEMM_PP_MINFILL", 50), knob_env("AF_GEMM_TILE", -1),
+    knob_env("AF_GEMM_PP_MINFILL", 50), knob_env("AF_GEMM_TILE", -1),
     knob_env("AF_GEMM_SPLITK", -1),    knob_env("AF_GEMM_GROUPM", -1),    knob_env("AF_GEMM_DMA", -1),
     knob_env("AF_PP_DIRECT", -1),      knob_env("AF_ATTN_RING", 1),
     knob_env("AF_GN_SMALL", 1),        knob_env("AF_CONV_TAP_INNER", 1),
@@ -56,18 +56,18 @@ AfKnobs g_af_knobs = {
     knob_env("AF_PP_STAGGER", 1),      knob_env("AF_GN_PRODUCER", 1),     knob_env("AF_CONV_UP_PHASE4", 1),
     knob_env("AF_PP_SCHED", 2),        knob_env("AF_ATTN_SHORT", 1),
     knob_env("AF_GEMM_M128", 1),       knob_env("AF_SMALL_M_TILE64", 1),  knob_env("AF_GN_CONSUMER", 1),
-    knob_env("AF_PLAN_LOG", 0)};
+    knob_env("AF_XATTN_FUSED", 1),     knob_env("AF_PLAN_LOG", 0)};
 static const AfKnobs g_af_knobs_initial = g_af_knobs;
 static int* knob_slot(const char* name) {
   static const struct { const char* n; int AfKnobs::*m; } tab[] = {
       {"splitk_target", &AfKnobs::splitk_target}, {"conv_halo", &AfKnobs::conv_halo}, {"gemm_pp", &AfKnobs::gemm_pp},
-      {"gemm_pp_geglu_minkt", &AfKnobs::gemm_pp_geglu_minkt}, {"gemm_pp_minfill", &AfKnobs::gemm_pp_minfill},
+      {"gemm_pp_minfill", &AfKnobs::gemm_pp_minfill},
       {"gemm_tile", &AfKnobs::gemm_tile}, {"gemm_splitk", &AfKnobs::gemm_splitk}, {"gemm_groupm", &AfKnobs::gemm_groupm},
       {"gemm_dma", &AfKnobs::gemm_dma}, {"pp_direct", &AfKnobs::pp_direct}, {"attn_ring", &AfKnobs::attn_ring},
       {"gn_small", &AfKnobs::gn_small}, {"conv_tap_inner", &AfKnobs::conv_tap_inner}, {"ln_fuse", &AfKnobs::ln_fuse},
       {"geglu_rowpanel", &AfKnobs::geglu_rowpanel}, {"conv_halo8", &AfKnobs::conv_halo8}, {"conv_fast_taps", &AfKnobs::conv_fast_taps}, {"pp_stagger", &AfKnobs::pp_stagger}, {"gn_producer", &AfKnobs::gn_producer}, {"conv_up_phase4", &AfKnobs::conv_up_phase4}, {"pp_sched", &AfKnobs::pp_sched},
       {"attn_short", &AfKnobs::attn_short},
-      {"gemm_m128", &AfKnobs::gemm_m128}, {"small_m_tile64", &AfKnobs::small_m_tile64}, {"gn_consumer", &AfKnobs::gn_consumer}, {"plan_log", &AfKnobs::plan_log}};
+      {"gemm_m128", &AfKnobs::gemm_m128}, {"small_m_tile64", &AfKnobs::small_m_tile64}, {"gn_consumer", &AfKnobs::gn_consumer}, {"xattn_fused", &AfKnobs::xattn_fused}, {"plan_log", &AfKnobs::plan_log}};
   if (!name) return nullptr;
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) return &(g_af_knobs.*(t.m));
@@ -191,6 +191,9 @@ struct XfmrBlockW {
   // LayerNorm folded into the consumer GEMM (bf16 mode): W * gamma, bias = W beta + b, column sums of W * gamma
   Linear qkv1_ln, q2_ln, ff1_ln;
   float *qkv1_cs = nullptr, *q2_cs = nullptr, *ff1_cs = nullptr;
+  // attn2.to_out with its K dimension permuted into the order in which xattn_fused_kernel's O^T accumulators come back as
+  // MFMA operands (bf16, C = 320 / 8 heads only; filled with the folded twins)
+  void* out2_perm = nullptr;
 };
 struct XfmrW {
   int C = 0, heads = 0, dh = 0;
@@ -233,6 +236,8 @@ struct CtxKV {  // cached cross-attention K/V for one transformer block
   int C = 0;
   void* vt = nullptr;   // V packed as the resident fragments of the short-key cross-attention kernel (bf16, dh 40 / 80), or null
   size_t vt_bytes = 0;
+  void* xf_pack = nullptr;   // K (pre-scaled) and V packed per head pair for xattn_fused_kernel (bf16, C = 320, <= 80 keys), or null
+  size_t xf_bytes = 0;
 };
 
 struct af_handle {
@@ -454,6 +459,7 @@ static int make_xfmr(Builder& b, const std::string& prefix, int C, int heads, in
       twin(t.qkv1, t.qkv1_ln, t.qkv1_cs);
       twin(t.q2, t.q2_ln, t.q2_cs);
       twin(t.ff1, t.ff1_ln, t.ff1_cs);
+      if (af_xattn_fused_pack_elems(1, heads, dh, 1) > 0 && inner == C) t.out2_perm = b.dmalloc((size_t)t.out2.rows_pad * t.out2.ldw * esize(h->dtype));
     }
     x.blocks.push_back(t);
   }
@@ -1156,7 +1162,44 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out, bool twin
       AF_TRY(dup(x));
     }
     // --- x = x + attn2(norm2(x), context) ---
-    Act q = R.alloc_act(B, H, W, C);
+    const CtxKV& kv = h->ctx_kv[w.ca_slot + d];
+    const int S = h->ctx_tokens;
+    if (!R.dry && (!kv.kv || h->ctx_Bf != B)) {
+      af_set_error_msg("context not set for batch %d (af_set_context)", B);
+      return AF_ERR_STATE;
+    }
+    const int ca_layer = (w.ca_slot + (int)d) / (int)w.blocks.size();
+    // subject-token conv attention: every conditioned layer except CA layers 6-10 (openaimodel.py:922-932)
+    const bool conv_attn = h->conv_ks >= 2 && !h->conv_batch.empty() && !(ca_layer >= 6 && ca_layer <= 10);
+    Act t2 = R.alloc_act(B, H, W, C);
+    Act q = R.alloc_act(B, H, W, C);              // (allocated either way: the arena's sizing pass must not depend on the choice below)
+    // ONE launch for the whole layer (bf16, C = 320 / 8 heads x 40, <= 80 keys, LayerNorm folded: the 64x64 level):
+    // LayerNorm-folded to_q, attention over the packed context K / V, to_out + bias + residual and the LayerNorm partial sums
+    // for norm3's consumer (af_xattn_fused.hip).  Decided from the shape and the weights alone, so that the sizing pass and
+    // the run agree; the pack exists whenever the context was set for such a layer
+    const bool fused_ca = g_af_knobs.xattn_fused && R.dt == AF_DTYPE_BF16 && ln_parts == 4 && !conv_attn && blk.out2_perm && blk.q2_ln.w &&
+                          t1.ld == C && t2.ld == C && af_xattn_fused_ok(B * N, N, C, w.heads, w.dh, S > 0 ? S : 77);
+    if (fused_ca) {
+      AF_TRY(R.check(t2));
+      if (pre) AF_TRY(finalize(st_1, blk.ln2, (long)Bh * N));   // the producer ran on the first half: (mu, rstd) serve both halves
+      if (pre && !R.dry)
+        HIP_CHECK_RET(hipMemcpyAsync(st_row + (size_t)Bh * N * 2, st_row, (size_t)Bh * N * 2 * sizeof(float), hipMemcpyDeviceToDevice, R.s));
+      if (!R.dry) {
+        if (!kv.xf_pack) { af_set_error_msg("fused cross-attention: no K / V pack for this layer (af_set_context)"); return AF_ERR_STATE; }
+        AfXattnFusedParams a;
+        memset(&a, 0, sizeof(a));
+        a.x = t1.p; a.ldx = t1.ld; a.M = B * N; a.rows_per_sample = N;
+        if (pre) { a.ln_stats = st_row; a.ln_parts_n = 0; }
+        else { a.ln_stats = st_1; a.ln_parts_n = ln_parts; a.ln_inv_count = 1.0f / (float)C; a.ln_eps = blk.ln2.eps; }
+        a.wq = blk.q2_ln.w; a.ldwq = blk.q2_ln.ldw; a.q_colsum = blk.q2_cs; a.q_bias = blk.q2_ln.bias;
+        a.kvpack = kv.xf_pack;
+        a.wo = blk.out2_perm; a.ldwo = blk.out2.ldw; a.o_bias = blk.out2.bias;
+        a.out = t2.p; a.ldo = t2.ld;
+        a.ln_stats_out = st_2;
+        a.Nk = S;
+        AF_TRY(af_launch_xattn_fused(a, R.s));
+      }
+    } else {
     if (ln_parts) {
       Runner::LnArgs ca = consumer(st_1, blk.q2_cs, blk.ln2);
       if (pre) {   // the producer ran on the first half: finalise its rows, (mu, rstd) serve the second half as well
@@ -1170,15 +1213,6 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out, bool twin
       AF_TRY(R.layernorm(blk.ln2, t1, n));
       AF_TRY(R.conv(blk.q2, n, q, 1, 0, nullptr, nullptr, 0));
     }
-    const CtxKV& kv = h->ctx_kv[w.ca_slot + d];
-    const int S = h->ctx_tokens;
-    if (!R.dry && (!kv.kv || h->ctx_Bf != B)) {
-      af_set_error_msg("context not set for batch %d (af_set_context)", B);
-      return AF_ERR_STATE;
-    }
-    const int ca_layer = (w.ca_slot + (int)d) / (int)w.blocks.size();
-    // subject-token conv attention: every conditioned layer except CA layers 6-10 (openaimodel.py:922-932)
-    const bool conv_attn = h->conv_ks >= 2 && !h->conv_batch.empty() && !(ca_layer >= 6 && ca_layer <= 10);
     if (!conv_attn) {
       AF_TRY(R.attention(q.p, C, (long)N * C, kv.kv, 2 * C, (long)S * 2 * C, R.dry ? nullptr : R.elem_ptr(kv.kv, C),
                          2 * C, (long)S * 2 * C, a, N, S, w.heads, w.dh, 0, -1, nullptr, 0, kv.vt, B > 0 ? kv.vt_bytes / (size_t)B : 0));
@@ -1219,10 +1253,10 @@ static int run_xfmr(Runner& R, const XfmrW& w, const Act& x, Act& out, bool twin
       }
       R.A.release(mk3);
     }
-    Act t2 = R.alloc_act(B, H, W, C);
     {
       const Runner::LnArgs pa = producer(st_2);
       AF_TRY(R.conv(blk.out2, a, t2, 1, 0, &t1, nullptr, 0, -1, -1, ln_parts ? &pa : nullptr));
+    }
     }
     // --- x = ff(norm3(x)) + x ---
     Act f = R.alloc_act(B, H, W, 4 * C);
@@ -1262,6 +1296,7 @@ static int fold_layernorms(af_handle* h, hipStream_t s) {
                                      t.q2.rows_pad, C, t.q2.ldw, s));
       AF_TRY(af_launch_ln_fold<bf16>(t.ff1.w, t.ff1_ln.w, t.ln3.gamma, t.ln3.beta, t.ff1.bias, t.ff1_cs, t.ff1_ln.bias,
                                      t.ff1.rows_pad, C, t.ff1.ldw, s));
+      if (t.out2_perm) AF_TRY(af_launch_xattn_fused_permute_wo(t.out2.w, t.out2.ldw, C, t.out2_perm, t.out2.ldw, s));
     }
   h->ln_fold_dirty = false;
   return 0;
@@ -1823,7 +1858,7 @@ void af_destroy(af_handle* h) {
   hipSetDevice(h->device);
   hipDeviceSynchronize();
   for (void* p : h->owned) hipFree(p);
-  for (auto& kv : h->ctx_kv) { if (kv.kv) hipFree(kv.kv); if (kv.vt) hipFree(kv.vt); }
+  for (auto& kv : h->ctx_kv) { if (kv.kv) hipFree(kv.kv); if (kv.vt) hipFree(kv.vt); if (kv.xf_pack) hipFree(kv.xf_pack); }
   if (h->ctx_rowmap) hipFree(h->ctx_rowmap);
   if (h->ctx_cast) hipFree(h->ctx_cast);
   if (h->arena.base) hipFree(h->arena.base);
@@ -1966,6 +2001,15 @@ int af_set_context(af_handle* h, const float* ctx_dev, int Bf, int n_tokens, int
         HIP_CHECK_RET(hipMalloc(&h->ctx_kv[i].vt, (size_t)pe * 2));
         h->ctx_kv[i].vt_bytes = (size_t)pe * 2;
       }
+      if (h->ctx_kv[i].xf_pack) hipFree(h->ctx_kv[i].xf_pack);
+      h->ctx_kv[i].xf_pack = nullptr;
+      h->ctx_kv[i].xf_bytes = 0;
+      const long xe = (dt == AF_DTYPE_BF16 && C == x.heads * x.dh && x.blocks[h->ca_list[i].second].out2_perm)
+                          ? af_xattn_fused_pack_elems(Bf, x.heads, x.dh, n_tokens) : 0;
+      if (xe > 0) {
+        HIP_CHECK_RET(hipMalloc(&h->ctx_kv[i].xf_pack, (size_t)xe * 2));
+        h->ctx_kv[i].xf_bytes = (size_t)xe * 2;
+      }
     }
   }
   if (h->conv_ks >= 2 && !h->conv_batch.empty()) {
@@ -2034,6 +2078,9 @@ int af_set_context(af_handle* h, const float* ctx_dev, int Bf, int n_tokens, int
     p.M = Bf * n_tokens; p.N = 2 * C; p.K = D;
     p.out = h->ctx_kv[i].kv; p.ldo = 2 * C; p.alpha = 1.0f;
     AF_TRY(DISPATCH(dt, af_launch_conv_gemm<bf16>(p, 1, s), af_launch_conv_gemm<float>(p, 1, s)));
+    if (h->ctx_kv[i].xf_pack)   // K (x scale log2 e) and V of this layer as the operand fragments of xattn_fused_kernel
+      AF_TRY(af_launch_xattn_fused_pack(h->ctx_kv[i].kv, 2 * C, (long)n_tokens * 2 * C, n_tokens, Bf, 1.0f / sqrtf((float)x.dh),
+                                        h->ctx_kv[i].xf_pack, s));
     if (h->ctx_kv[i].vt)   // V of this layer as resident fragments (rows of the key list as they now stand)
       AF_TRY(af_launch_attn_short_pack<bf16>(reinterpret_cast<char*>(h->ctx_kv[i].kv) + (size_t)C * 2, 2 * C, (long)n_tokens * 2 * C,
                                              n_tokens, x.heads, x.dh, Bf, h->ctx_kv[i].vt, s));
@@ -2272,6 +2319,7 @@ int af_gemm_plan_counts(int64_t* counts10) {
 }
 int af_gemm_plan_counts_reset(void) {
   g_af_attn_short_launches = 0;
+  g_af_xattn_fused_launches = 0;
   g_af_gn_consumer_launches = 0;
   for (int i = 0; i < 15; ++i) g_af_plan_counts[i] = 0;
   return AF_OK;
@@ -2282,6 +2330,7 @@ int64_t af_rowpanel_launches(void) { return g_af_plan_counts[12]; }
 int64_t af_up_phase4_launches(void) { return g_af_plan_counts[13]; }
 int64_t af_gn_producer_launches(void) { return g_af_plan_counts[14]; }
 int64_t af_attn_short_launches(void) { return g_af_attn_short_launches; }
+int64_t af_xattn_fused_launches(void) { return g_af_xattn_fused_launches; }
 int64_t af_gn_consumer_launches(void) { return g_af_gn_consumer_launches; }
 int af_set_fp8(af_handle* h, int on) {
   if (!h) { af_set_error_msg("af_set_fp8: null handle"); return AF_ERR_INVALID; }

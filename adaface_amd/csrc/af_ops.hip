@@ -488,6 +488,53 @@ int af_op_attention(int dtype, const float* q_dev, const float* k_dev, const flo
   return 0;
 }
 
+// One cross-attention layer through xattn_fused_kernel (bf16), prepared as the model prepares it: LayerNorm folded into to_q
+// (af_launch_ln_fold), K / V packed per head pair, to_out's K dimension permuted.  ln_parts_out_dev (optional): [4][B * N][2]
+// partial sums of the stored rows, as the next LayerNorm's consumer reads them.
+int af_op_xattn_fused(const float* x_dev, const float* ln_stats_dev, const float* gamma_dev, const float* beta_dev,
+                      const float* wq_dev, const float* kv_dev, const float* wo_dev, const float* bo_dev, float* y_dev,
+                      float* ln_parts_out_dev, int B, int N, int S, void* stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Tmp tmp;
+  constexpr int C = 320, Hh = 8, dh = 40;
+  const int M = B * N, rows_pad = rup(C, 128);
+  if (!af_xattn_fused_ok(M, N, C, Hh, dh, S)) { af_set_error_msg("af_op_xattn_fused: B=%d N=%d S=%d has no fused kernel", B, N, S); return AF_ERR_INVALID; }
+  OP_ALLOC(xn, (size_t)M * C * 2, false);
+  OP_ALLOC(yn, (size_t)M * C * 2, true);
+  OP_ALLOC(wq, (size_t)rows_pad * C * 2, true);
+  OP_ALLOC(wqf, (size_t)rows_pad * C * 2, true);
+  OP_ALLOC(wo, (size_t)rows_pad * C * 2, true);
+  OP_ALLOC(wop, (size_t)rows_pad * C * 2, true);
+  OP_ALLOC(cs, (size_t)rows_pad * 4, true);
+  OP_ALLOC(bf, (size_t)rows_pad * 4, true);
+  OP_ALLOC(kvn, (size_t)B * S * 2 * C * 2, false);
+  const long pe = af_xattn_fused_pack_elems(B, Hh, dh, S);
+  OP_ALLOC(pack, (size_t)pe * 2, false);
+  OP_ALLOC(parts, (size_t)4 * M * 2 * sizeof(float), true);
+  OP_TRY(af_launch_cast_f32<bf16>(x_dev, xn, (long)M * C, s));
+  OP_TRY(af_launch_cast_f32<bf16>(kv_dev, kvn, (long)B * S * 2 * C, s));
+  OP_TRY(af_launch_repack_weight<bf16>(wq_dev, wq, C, C, C, 1, C, 0, 0, s));
+  OP_TRY(af_launch_repack_weight<bf16>(wo_dev, wo, C, C, C, 1, C, 0, 0, s));
+  OP_TRY(af_launch_ln_fold<bf16>(wq, wqf, gamma_dev, beta_dev, nullptr, (float*)cs, (float*)bf, rows_pad, C, C, s));
+  OP_TRY(af_launch_xattn_fused_permute_wo(wo, C, C, wop, C, s));
+  OP_TRY(af_launch_xattn_fused_pack(kvn, 2 * C, (long)S * 2 * C, S, B, 1.0f / sqrtf((float)dh), pack, s));
+  AfXattnFusedParams a;
+  memset(&a, 0, sizeof(a));
+  a.x = xn; a.ldx = C; a.M = M; a.rows_per_sample = N;
+  a.ln_stats = ln_stats_dev; a.ln_parts_n = 0;
+  a.wq = wqf; a.ldwq = C; a.q_colsum = (const float*)cs; a.q_bias = (const float*)bf;
+  a.kvpack = pack;
+  a.wo = wop; a.ldwo = C; a.o_bias = bo_dev;
+  a.out = yn; a.ldo = C;
+  a.ln_stats_out = (float*)parts;
+  a.Nk = S;
+  OP_TRY(af_launch_xattn_fused(a, s));
+  OP_TRY(af_launch_cast_to_f32<bf16>(yn, y_dev, (long)M * C, s));
+  if (ln_parts_out_dev && hipMemcpyAsync(ln_parts_out_dev, parts, (size_t)4 * M * 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return AF_ERR_HIP;
+  return 0;
+}
+
 int af_op_timestep_embedding(int dtype, const int64_t* t_dev, float* y_dev, int B, int dim, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Tmp tmp;

@@ -171,6 +171,26 @@ def attention(q, k, v, heads, scale=None, dtype="bf16", causal=False, nan_guard=
     return o
 
 
+def xattn_fused(x, gamma, beta, wq, kv, wo, bo, eps=1e-5):
+    """One cross-attention layer of a 64x64-level BasicTransformerBlock in ONE kernel (bf16; attention.py:172-257, 279):
+    y = x + to_out(softmax(to_q(LayerNorm(x)) K^T / sqrt(40)) V) with x [B, N, 320], kv [B, S, 640] = the context's K | V
+    projections.  Returns (y, parts) with parts [4, B * N, 2] = the LayerNorm partial sums (sum, sum of squares) of the stored
+    rows, as the next consumer reads them."""
+    lib = _lib.load()
+    x = _dev_f32(x)
+    B, N, Cn = x.shape
+    S = kv.shape[1]
+    xb = x.to(torch.bfloat16).float().reshape(B * N, Cn)            # statistics of the rows the kernel reads
+    mu = xb.mean(dim=1)
+    var = (xb * xb).mean(dim=1) - mu * mu
+    stats = torch.stack([mu, torch.rsqrt(var.clamp_min(0) + eps)], dim=1).contiguous()
+    y = torch.empty_like(x)
+    parts = torch.empty(4, B * N, 2, device=x.device, dtype=torch.float32)
+    check(lib.af_op_xattn_fused(ptr(x), ptr(stats), ptr(_dev_f32(gamma)), ptr(_dev_f32(beta)), ptr(_dev_f32(wq)), ptr(_dev_f32(kv)),
+                                ptr(_dev_f32(wo)), ptr(_dev_f32(bo)), ptr(y), ptr(parts), B, N, S, stream_ptr()), "af_op_xattn_fused")
+    return y, parts
+
+
 def timestep_embedding(t, dim, dtype="f32"):
     lib = _lib.load()
     t = t.contiguous().long()

@@ -206,10 +206,10 @@ int af_gemm_plan_counts_reset(void);
  * launch path reads the environment.  The parity tests use af_knob_set to reach a kernel variant regardless of the
  * planner's choice and af_knob_reset to restore the load-time values.  No knob changes results beyond the summation
  * order of the chosen tiling.  The 26 names (adaface_amd/csrc/af_common.h, struct AfKnobs): splitk_target, conv_halo, gemm_pp,
- * gemm_pp_geglu_minkt, gemm_pp_minfill, gemm_tile, gemm_splitk, gemm_groupm, gemm_dma, pp_direct, attn_ring, gn_small,
+ * gemm_pp_minfill, gemm_tile, gemm_splitk, gemm_groupm, gemm_dma, pp_direct, attn_ring, gn_small,
  * conv_tap_inner, ln_fuse, geglu_rowpanel, conv_halo8, conv_fast_taps, pp_stagger, gn_producer, conv_up_phase4, pp_sched,
- * attn_short, gemm_m128, small_m_tile64, gn_consumer, plan_log.  Round 4 removed the five that selected a measured-neutral or
- * slower variant (gn_reduce, splitk_inlaunch, rowpanel_deep, gn_fold, attn_w4; numbers in DESIGN.md section 5). */
+ * attn_short, gemm_m128, small_m_tile64, gn_consumer, xattn_fused, plan_log.  Round 4 removed the six that selected a measured-neutral or
+ * slower variant or nothing at all (gn_reduce, splitk_inlaunch, rowpanel_deep, gn_fold, attn_w4, gemm_pp_geglu_minkt; numbers in DESIGN.md section 5). */
 int af_knob_set(const char* name, int value);
 int af_knob_get(const char* name, int* value);
 int af_knob_reset(void);
@@ -247,6 +247,15 @@ int64_t af_gn_producer_launches(void); /* convolutions that also wrote the Group
 /* launches of the register-resident short-key cross-attention kernel (bf16, <= 96 keys, dh 40 / 80) since the last
  * af_gemm_plan_counts_reset */
 int64_t af_attn_short_launches(void);
+/* launches of the one-kernel cross-attention layer (bf16, C = 320, 8 heads x 40, <= 80 keys: LayerNorm-folded to_q + attention +
+ * to_out + residual; adaface_amd/csrc/af_xattn_fused.hip) since the last af_gemm_plan_counts_reset */
+int64_t af_xattn_fused_launches(void);
+/* the same layer as an operator (parity tests; /root/reference/ldm/modules/attention.py:172-257, 279): x [B, N, 320] fp32,
+ * ln_stats [B * N][2] = (mean, rstd) of the bf16-rounded rows, gamma / beta [320], wq [320, 320] (to_q, no bias), kv [B, S, 640]
+ * = the context's K | V projections, wo [320, 320] + bo [320] (to_out); y = x + to_out(softmax(to_q(LN(x)) K^T / sqrt(40)) V) */
+int af_op_xattn_fused(const float* x_dev, const float* ln_stats_dev, const float* gamma_dev, const float* beta_dev,
+                      const float* wq_dev, const float* kv_dev, const float* wo_dev, const float* bo_dev, float* y_dev,
+                      float* ln_parts_out_dev, int B, int N, int S, void* stream);
 /* row-panel GEMM launches that applied the GroupNorm of their input in their prologue (SpatialTransformer.norm + proj_in) */
 int64_t af_gn_consumer_launches(void);
 int64_t af_up_phase4_launches(void); /* upsampled 3x3 convolutions run as four 2x2 phase convolutions on the stored map */

@@ -122,6 +122,15 @@ if args.only in ("", "attn"):
         tot += ms * cnt
     print(f"  attention weighted total per forward: {tot:.2f} ms")
 
+if args.only in ("", "attn", "xattn") and args.dtype == "bf16":
+    # the cross-attention LAYER of a 64x64-level BasicTransformerBlock as one kernel (to_q + attention + to_out + residual),
+    # next to the three launches it replaces (timed above: linear [M,320]->320 twice + attention N4096 S77 d40)
+    N, S, Cn = 4096, 77, 320
+    x = rn(Bf, N, Cn); gamma = rn(Cn) * 0.2 + 1; beta = rn(Cn) * 0.2; wq = rn(Cn, Cn) * Cn ** -0.5; wo = rn(Cn, Cn) * Cn ** -0.5
+    bo = rn(Cn) * 0.1; kv = rn(Bf, S, 2 * Cn)
+    ms, fl, by = timed(1, lambda: ops.xattn_fused(x, gamma, beta, wq, kv, wo, bo))
+    show(f"cross-attention layer fused N{N} S{S} C{Cn} (x5)", ms, fl, by)
+
 if args.only in ("", "norm"):
     gns = [(320, 64, 13), (640, 64, 2), (960, 64, 1), (320, 32, 1), (640, 32, 11), (1280, 32, 1), (1920, 32, 1),
            (640, 16, 1), (1280, 16, 11), (2560, 16, 2), (1280, 8, 12), (2560, 8, 3)]

@@ -331,16 +331,17 @@ def test_sd15_unet_layernorm_folding_ab(gpu, report, knobs):
     knobs("ln_fuse", 0)
     eps_plain = eng.unet_forward(x, t)
     pc0 = _lib.plan_counts(reset=True)
-    assert pc["ln_consumer"] == 30 and pc0["ln_consumer"] == 0 and pc0["ln_producer"] == 0, (pc, pc0)
+    assert pc["ln_consumer"] == 25 and pc["xattn_fused"] == 5 and pc0["ln_consumer"] == 0 and pc0["ln_producer"] == 0 and pc0["xattn_fused"] == 0, (pc, pc0)
     eng.close()
     ref = _f32_mode_forward(gpu, cfg, 36, x, t, ctx, 16)
     _assert_bf16_ab(report, "sd15_unet Bf=16 LayerNorm-folded (A) vs stand-alone LayerNorm (B)", eps_fused, eps_plain, ref)
 
 
 def test_sd15_unet_new_fused_paths_ab(gpu, report, knobs):
-    """Round-3 fusions at the benchmark batch, each against the forward without it (knob off) and both against the f32-mode
-    forward (derived bf16 bars, _assert_bf16_ab): the register-resident short-key cross-attention kernel, and the
-    SpatialTransformer GroupNorm applied in the prologue of the row-panel proj_in."""
+    """Round-3 / round-4 fusions at the benchmark batch, each against the forward without it (knob off) and both against the
+    f32-mode forward (derived bf16 bars, _assert_bf16_ab, unchanged): the cross-attention layer of the 64x64 level as one
+    kernel (xattn_fused_kernel: to_q + attention + to_out + residual), the register-resident short-key cross-attention
+    kernel, and the SpatialTransformer GroupNorm applied in the prologue of the row-panel proj_in."""
     from adaface_amd import _lib
     from adaface_amd.engine import Engine
     from adaface_amd.synth import synth_weights_into
@@ -355,14 +356,20 @@ def test_sd15_unet_new_fused_paths_ab(gpu, report, knobs):
     _lib.plan_counts(reset=True)
     full = eng.unet_forward(x, t)
     pc = _lib.plan_counts(reset=True)
-    assert pc["attn_short"] == 10 and pc["gn_consumer"] == 5, pc
+    # (the five cross-attention layers of the 64x64 level run as ONE kernel each, round 4: the short-key kernel keeps the 32x32 level)
+    assert pc["attn_short"] == 5 and pc["gn_consumer"] == 5 and pc["xattn_fused"] == 5, pc
     outs = {}
-    for knob in ("attn_short", "gn_consumer"):
+    for knob in ("xattn_fused", "attn_short", "gn_consumer"):
         knobs(knob, 0)
+        if knob == "attn_short":
+            knobs("xattn_fused", 0)           # (all ten short-key launches on the flash kernel: the round-3 A/B)
         outs[knob] = eng.unet_forward(x, t)
         pc0 = _lib.plan_counts(reset=True)
         assert pc0[knob] == 0, pc0
+        if knob == "xattn_fused":
+            assert pc0["attn_short"] == 10, pc0   # three launches per layer again
         knobs(knob, 1)
+        knobs("xattn_fused", 1)
     eng.close()
     ref = _f32_mode_forward(gpu, cfg, 62, x, t, ctx, 16)
     for knob, out in outs.items():
@@ -427,13 +434,15 @@ def test_sd15_unet_batch_consistency(gpu, report):
         if dtype == "bf16":      # the launches the benchmark times: eight-wave ping-pong tiles and a sliced-K launch,
             # and the LayerNorm-folded GEMMs of the 64x64 and 32x32 transformers (3 consumers + 3 producers each)
             assert pc["tile4"] > 0 and pc["tile5"] > 0 and pc["splitk"] > 0, pc
-            assert pc["ln_consumer"] == 30 and pc["ln_producer"] == 30, pc
+            # (round 4: the 64x64 level's attn2.to_q consumer and attn2.to_out producer live inside xattn_fused_kernel: 30 - 5 each)
+            assert pc["ln_consumer"] == 25 and pc["ln_producer"] == 25, pc
             # the three Upsample convolutions as four 2x2 phase convolutions; row-panel GEMMs at the 64x64 and 32x32 levels
-            assert pc["up_phase4"] == 3 and pc["rowpanel"] >= 35, pc
+            assert pc["up_phase4"] == 3 and pc["rowpanel"] >= 25, pc
             # ResBlock convolutions at the 64x64 / 32x32 levels that also summed the GroupNorm statistics of their output
             assert pc["gn_producer"] >= 15, pc
-            # the ten cross-attention layers of the 64x64 / 32x32 levels on the register-resident short-key kernel
-            assert pc["attn_short"] == 10, pc
+            # the five cross-attention layers of the 64x64 level as ONE kernel each, those of the 32x32 level on the
+            # register-resident short-key kernel
+            assert pc["xattn_fused"] == 5 and pc["attn_short"] == 5, pc
             # ... and the GroupNorm of the 64x64-level ones applied in the prologue of the row-panel proj_in
             assert pc["gn_consumer"] == 5, pc
             e16 = (eps16 - eps_f32).abs().max().item() / eps_f32.abs().max().item()

@@ -414,7 +414,6 @@ def test_linear_pingpong(gpu, report, knobs, M, K, N, bias, res, geglu):
     """Linear / GEGLU through the ping-pong kernel (GEGLU: 256x128 tile, value|gate interleaved in 16-row groups)."""
     from adaface_amd import ops
     knobs("gemm_pp_minfill", 0)
-    knobs("gemm_pp_geglu_minkt", 0)
     dtype = "bf16"
     g = torch.Generator().manual_seed(M + K + N + 1)
     x = _q(torch.randn(M, K, generator=g), dtype)
@@ -637,6 +636,53 @@ def test_attention_short_keys_register_resident(gpu, report, knobs, B, Nq, Nk, h
     d = (got - flash).abs().max().item()
     report(f"attention short-key vs flash kernel N{Nq} S{Nk} d{dh}[bf16]", d, ref.abs().max().item(), 2 * TOL["bf16"] * ref.abs().max().item())
     assert d <= 2 * TOL["bf16"] * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("B,N,S", [(2, 4096, 77), (3, 1024, 80), (1, 256, 33), (2, 512, 1), (1, 768, 64)])
+def test_cross_attention_layer_in_one_kernel(gpu, report, B, N, S):
+    """xf::xattn_fused_kernel -- x + to_out(softmax(to_q(LayerNorm(x)) K^T / sqrt(dh)) V) of a 64x64-level BasicTransformerBlock
+    (attention.py:172-257, 279) in ONE launch -- against the torch restatement of those lines on the same bf16-rounded operands,
+    and against the three launches it replaces (LayerNorm + to_q, short-key attention, to_out + residual through the op-level
+    entry points).  Ragged key counts (1, 33, 64, 77, 80: masks on a partial key block, an empty upper half of the last PV k
+    step), several samples per launch (the K / V pack is per sample).  Also the LayerNorm partial sums the kernel leaves for
+    norm3's consumer: sum and sum of squares of the rows it stored."""
+    from adaface_amd import _lib, ops
+    g = torch.Generator().manual_seed(B * 1000 + N + S)
+    C, heads, dh = 320, 8, 40
+    x = _q(torch.randn(B, N, C, generator=g) * 1.4 + 0.3 * torch.randn(B, N, 1, generator=g), "bf16")
+    gamma = torch.randn(C, generator=g) * 0.2 + 1.0
+    beta = torch.randn(C, generator=g) * 0.2
+    wq = _q(torch.randn(C, C, generator=g) / math.sqrt(C), "bf16")
+    wo = _q(torch.randn(C, C, generator=g) / math.sqrt(C), "bf16")
+    bo = torch.randn(C, generator=g) * 0.1
+    kv = _q(torch.randn(B, S, 2 * C, generator=g) * torch.tensor([1.0] * C + [1.5] * C), "bf16")
+    k, v = kv[..., :C], kv[..., C:]
+    # reference (fp32): attention.py:279 x + attn2(norm2(x), context); :190 q = to_q(x); :197-243 softmax(q k^T scale) v; :245 to_out
+    ln = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    q = ln @ wq.t()
+    o = _ref_attention(q, k, v, heads)
+    ref = x + o @ wo.t() + bo
+    _lib.plan_counts(reset=True)
+    got, parts = ops.xattn_fused(x.to(gpu), gamma.to(gpu), beta.to(gpu), wq.to(gpu), kv.to(gpu), wo.to(gpu), bo.to(gpu))
+    assert _lib.plan_counts(reset=True)["xattn_fused"] == 1
+    _cmp(report, f"cross-attention layer fused B{B} N{N} S{S}", got, ref, "bf16")
+    # the three launches: LayerNorm -> to_q, attention (short-key kernel), to_out + residual
+    lnq = ops.layer_norm(x.reshape(B * N, C).to(gpu), gamma.to(gpu), beta.to(gpu), dtype="bf16")
+    qq = ops.linear(lnq, wq.to(gpu), None, None, dtype="bf16").reshape(B, N, C)
+    oo = ops.attention(qq, k.contiguous().to(gpu), v.contiguous().to(gpu), heads, dtype="bf16")
+    plain = ops.linear(oo.reshape(B * N, C), wo.to(gpu), bo.to(gpu), x.reshape(B * N, C).to(gpu), dtype="bf16").reshape(B, N, C)
+    _cmp(report, f"cross-attention layer three launches B{B} N{N} S{S}", plain, ref, "bf16")
+    d = (got - plain).abs().max().item()
+    sc = ref.abs().max().item()
+    report(f"cross-attention layer fused vs three launches B{B} N{N} S{S}[bf16]", d, sc, 2 * TOL["bf16"] * sc)
+    assert d <= 2 * TOL["bf16"] * sc
+    # LayerNorm partial sums of the STORED (bf16) rows: parts 0 / 2 = columns 0-159 / 160-319, parts 1 / 3 zero
+    st = got.reshape(B * N, C).double()
+    assert float(parts[1].abs().max()) == 0.0 and float(parts[3].abs().max()) == 0.0
+    for part, lo in ((0, 0), (2, 160)):
+        s1, s2 = st[:, lo:lo + 160].sum(dim=1), (st[:, lo:lo + 160] ** 2).sum(dim=1)
+        assert torch.allclose(parts[part][:, 0].double(), s1, rtol=1e-4, atol=1e-3)
+        assert torch.allclose(parts[part][:, 1].double(), s2, rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.parametrize("Nk", [77, 129])
