@@ -459,7 +459,7 @@ static int make_xfmr(Builder& b, const std::string& prefix, int C, int heads, in
       twin(t.qkv1, t.qkv1_ln, t.qkv1_cs);
       twin(t.q2, t.q2_ln, t.q2_cs);
       twin(t.ff1, t.ff1_ln, t.ff1_cs);
-      if (af_xattn_fused_pack_elems(1, heads, dh, 1) > 0 && inner == C) t.out2_perm = b.dmalloc((size_t)t.out2.rows_pad * t.out2.ldw * esize(h->dtype));
+      if (af_xattn_fused_pack_elems(1, heads, dh, 77) > 0 && inner == C) t.out2_perm = b.dmalloc((size_t)t.out2.rows_pad * t.out2.ldw * esize(h->dtype));
     }
     x.blocks.push_back(t);
   }
