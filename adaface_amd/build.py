@@ -19,7 +19,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 BUILD = PKG / "_build"
 LIB = PKG / "libadaface_hip.so"
-SOURCES = ["af_conv_gemm.hip", "af_norm.hip", "af_attention.hip", "af_xattn_fused.hip", "af_elementwise.hip", "af_model.hip", "af_ops.hip"]
+SOURCES = ["af_conv_gemm.hip", "af_norm.hip", "af_attention.hip", "af_xattn_fused.hip", "af_conv_s8.hip", "af_elementwise.hip", "af_model.hip", "af_ops.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-Wno-unused-value",
          # MFMA accumulators in VGPRs (gfx950 has one unified register file): no v_accvgpr_read/write around the

@@ -94,7 +94,8 @@ struct AfKnobs {
                             //                         GEMMs of the 64x64-level transformers too, 3 = and its K = 640 form (GEGLU and
                             //                         q / k / v of the 32x32 level, >= 16384 rows), 4 = and the K = 1280 form
                             //                         ([>= 4096, 1280] -> 1280 of the 16x16 level)
-  int conv_halo8;           // AF_CONV_HALO8           0 = 3x3 / stride-1 convs stay on the gathering eight-wave kernel (no LDS halo)
+  int conv_halo8;           // AF_CONV_HALO8           bit 0: 3x3 / stride-1 convs of the 64x64 / 32x32 / 16x16 maps on conv3x3_halo8_kernel,
+                            //                         bit 1: those of the 8x8 maps on conv3x3_s8_kernel; 0 = all on the gathering kernel
   int conv_fast_taps;       // AF_CONV_FAST_TAPS       0 = ping-pong convs recompute every tap's bounds check in the staging phase
   int pp_stagger;           // AF_PP_STAGGER           merged schedule: 1 = the two wave groups issue their LDS-DMA pieces behind alternate MFMAs
   int gn_producer;          // AF_GN_PRODUCER          0 = GroupNorm always runs its own statistics pass (no sums from the producer convolution)

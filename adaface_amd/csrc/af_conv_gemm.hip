@@ -2795,15 +2795,23 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
   // the phased gathering kernel measured 3 % ahead: 388 vs 401 us)
   if (pl.tile == 5 && pl.halo_tw == 0 && p.ks == 3 && p.stride == 1 && p.pad == 1 && p.up == 0 && p.Ho == p.Hi && p.Wo == p.Wi &&
       (p.Wo == 16 || p.Wo == 32 || p.Wo == 64) && (p.Ho & (p.Ho - 1)) == 0 && p.Ho >= 256 / p.Wo && p.M % 256 == 0 &&
-      p.K == 9 * p.Cin && p.ldc >= p.Cin && g_af_knobs.conv_halo8 && !p.ln_stats && !p.ln_stats_out) {
+      p.K == 9 * p.Cin && p.ldc >= p.Cin && (g_af_knobs.conv_halo8 & 1) && !p.ln_stats && !p.ln_stats_out) {
     pl.halo_tw = 256;
     while (pl.splitk > 1 && (p.Cin / 64) % pl.splitk != 0) --pl.splitk;   // a K slice = whole channel chunks
+  }
+  // 8 x 8 maps (round 4): tiles of four whole images x 80 columns over four K slices, the images' halos resident in LDS
+  // (conv3x3_s8_kernel, af_conv_s8.hip); halo_tw = 8 names it
+  if (elem_size == 2 && (g_af_knobs.conv_halo8 & 2) && g_af_knobs.gemm_pp && af_conv_s8_ok(p, batch) && !p.gn_stats_out) {
+    pl.tile = 5;
+    pl.halo_tw = 8;
+    pl.splitk = 4;
   }
   const int ft = g_af_knobs.gemm_tile;
   if (ft >= 0 && ft < 4 && !(geglu && bn[ft] != 128)) pl.tile = ft;
   const int fs = g_af_knobs.gemm_splitk;
   if (fs >= 1 && batch == 1 && !geglu) pl.splitk = fs > KT ? KT : fs;
-  if (pl.splitk > 1 && pl.halo_tw != 256) pl.halo_tw = 0;
+  if (pl.halo_tw == 8 && (pl.tile != 5 || pl.splitk != 4)) pl.halo_tw = 0;   // (a forced tile / slice count: the generic kernels)
+  if (pl.splitk > 1 && pl.halo_tw != 256 && pl.halo_tw != 8) pl.halo_tw = 0;
   if (pl.halo_tw == 256 && (pl.tile != 5 || (p.Cin / 64) % pl.splitk != 0)) pl.halo_tw = 0;
   if (pl.splitk > 1) pl.ws_bytes = (size_t)pl.splitk * p.M * p.N * sizeof(float);
   plan_group_m(pl, p);
@@ -2815,7 +2823,7 @@ static void plan_group_m(AfGemmPlan& pl, const ConvGemmParams& p) {
   {
     // grouped tile order: minimise  X_bytes * (NT / gn) + W_bytes * (MT / gm)  with gm * gn = workgroups resident
     // per XCD (32 CUs x blocks per CU)
-    const bool h4 = pl.halo_tw != 0 && pl.halo_tw != 256;   // the four-wave halo kernel (128-pixel patches)
+    const bool h4 = pl.halo_tw != 0 && pl.halo_tw != 256 && pl.halo_tw != 8;   // the four-wave halo kernel (128-pixel patches)
     const int tbm = h4 ? 128 : (pl.tile >= 4 ? 256 : bm[pl.tile]);
     const int tbn = h4 ? ((pl.tile == 0 || pl.tile == 1) ? 128 : 64) : (pl.tile == 5 ? 160 : pl.tile == 4 ? 128 : bn[pl.tile]);
     const int MT = (p.M + tbm - 1) / tbm, NT = (p.N + tbn - 1) / tbn;
@@ -3188,7 +3196,7 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
     fprintf(stderr, "[af plan] M=%ld N=%d K=%d ks=%d stride=%d up=%d HoWo=%dx%d batch=%d tile=%d halo=%d splitk=%d rowpanel=%d res=%d geglu=%d ln=%d\n",
             (long)p.M, p.N, p.K, p.ks, p.stride, p.up, p.Ho, p.Wo, batch, pl.tile, pl.halo_tw, pl.splitk, af_conv_rowpanel_kind(p, batch),
             p.residual ? 1 : 0, p.epilogue == AF_EPI_GEGLU ? 1 : 0, (p.ln_stats || p.ln_stats_out) ? 1 : 0);
-  g_af_plan_counts[(pl.halo_tw && pl.halo_tw != 256) ? 6 : (pl.tile >= 0 && pl.tile < 6 ? pl.tile : 0)] += 1;
+  g_af_plan_counts[(pl.halo_tw && pl.halo_tw != 256 && pl.halo_tw != 8) ? 6 : (pl.tile >= 0 && pl.tile < 6 ? pl.tile : 0)] += 1;
   if (pl.halo_tw == 256) g_af_plan_counts[11] += 1;
   if (pl.splitk > 1) g_af_plan_counts[7] += 1;
   if (p.ln_stats) g_af_plan_counts[8] += 1;
@@ -3245,6 +3253,21 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
       case 6: return launch_gemm_m128(p, stream);
       default: break;
     }
+  }
+  if (pl.halo_tw == 8) {
+    if constexpr (sizeof(T) == 2) {
+      rc = af_launch_conv_s8(p, stream);
+    } else {
+      af_set_error_msg("conv_gemm: the 8 x 8-map kernel is bf16 only");
+      return -1;
+    }
+    if (rc) return rc;
+    const long nq = (long)p.M * (p.N >> 2);
+    unsigned blocks = (unsigned)((nq + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, stream, p);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
   }
   if (pl.halo_tw == 256) {
     if constexpr (sizeof(T) == 2) {

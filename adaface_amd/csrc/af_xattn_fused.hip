@@ -452,6 +452,13 @@ __global__ __launch_bounds__(512) void xattn_fused_kernel(const Params p) {
             sc[j][kb] = mma(kf[kb][1], qC[pr / 2][j], sc[j][kb]);
           }
         });
+        // every S^T MFMA is ISSUED here: hipcc otherwise sinks some of them into the v_max3 chains below, which read their
+        // results from inline asm -- no hazard padding there -- a few cycles too early on the younger wave of a SIMD (seen: the
+        // row maximum, and with it the bf16 rounding of P, changed from run to run on waves 4-7)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(sc[j][kb]));
       }
       // V^T fragments of this head (own blocks 0, 1 + its rows of the shared block): read once, used by both row blocks
       constexpr unsigned vbase = (unsigned)((K_FRAGS + hh * 3 * NSP) * 1024);

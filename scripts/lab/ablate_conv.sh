@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../.."
 if [ "$1" = build ]; then
   mkdir -p scripts/lab/ab /tmp/af_lab
   F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form"
-  for f in af_conv_gemm af_attention af_elementwise af_model af_norm af_ops; do
+  for f in af_conv_gemm af_attention af_xattn_fused af_conv_s8 af_elementwise af_model af_norm af_ops; do
     hipcc $F $([ $f = af_conv_gemm ] && echo -DAF_LAB_ABLATE=1) -c adaface_amd/csrc/$f.hip -o /tmp/af_lab/$f.o &
   done
   wait

@@ -368,6 +368,39 @@ def test_plain_rowpanel(gpu, report, knobs, M, K, N, bias, res):
     assert torch.equal(got, tiled), (got - tiled).abs().max().item()
 
 
+@pytest.mark.parametrize("B,Cin,Cout,bias,res", [
+    (16, 1280, 1280, True, True),     # the 8x8-level ResBlock convolution at the benchmark batch: 4 row tiles x 16 column tiles x 4 slices
+    (16, 2560, 1280, True, False),    # the skip-concatenated input: ten chunks per slice
+    (4, 256, 80, False, True),        # one row tile, one column tile, ONE chunk per slice (the next chunk's halo pieces are all dead)
+    (8, 512, 160, True, False),       # two chunks per slice: both halo buffers
+])
+def test_conv2d_8x8_maps(gpu, report, knobs, B, Cin, Cout, bias, res):
+    """conv3x3_s8_kernel (3x3 / stride 1 on 8 x 8 maps: tiles of four whole images x 80 columns over four K slices, the images'
+    halos resident in LDS) against torch, against the gathering kernel it replaces (knob conv_halo8 bit 1 off), run to run
+    bit-identical (slabs summed in slice order)."""
+    from adaface_amd import _lib, ops
+    g = torch.Generator().manual_seed(B + Cin + Cout)
+    x = _q(torch.randn(B, Cin, 8, 8, generator=g), "bf16")
+    w = _q(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin), "bf16")
+    b = torch.randn(Cout, generator=g) if bias else None
+    r = _q(torch.randn(B, Cout, 8, 8, generator=g), "bf16") if res else None
+    ref = F.conv2d(x, w, b, padding=1) + (r if res else 0)
+    run = lambda: ops.conv2d(x.to(gpu), w.to(gpu), b.to(gpu) if bias else None, residual=r.to(gpu) if res else None, dtype="bf16")
+    got = run()
+    tile, sk, halo = _last_plan()
+    assert tile == 5 and halo == 8 and sk == 4, (tile, sk, halo)
+    _cmp(report, f"conv3x3 8x8 maps {Cin}->{Cout} B{B}", got, ref, "bf16")
+    for _ in range(5):
+        assert torch.equal(run(), got)
+    knobs("conv_halo8", 1)
+    old = run()
+    assert _last_plan()[2] != 8
+    d = (got - old).abs().max().item()
+    sc = ref.abs().max().item()
+    report(f"conv3x3 8x8 maps vs gathering kernel {Cin}->{Cout} B{B}[bf16]", d, sc, 2 * TOL["bf16"] * sc)
+    assert d <= 2 * TOL["bf16"] * sc
+
+
 @pytest.mark.parametrize("B,Cin,H,W,Cout,bias,res,splitk", [
     (2, 320, 64, 64, 320, True, True, 1),      # the dominant ResBlock conv: 4-row tiles of a 64-wide image, 5 chunks (odd K)
     (1, 64, 64, 64, 160, True, False, 1),      # one chunk: the prologue's halo only
@@ -666,6 +699,11 @@ def test_cross_attention_layer_in_one_kernel(gpu, report, B, N, S):
     got, parts = ops.xattn_fused(x.to(gpu), gamma.to(gpu), beta.to(gpu), wq.to(gpu), kv.to(gpu), wo.to(gpu), bo.to(gpu))
     assert _lib.plan_counts(reset=True)["xattn_fused"] == 1
     _cmp(report, f"cross-attention layer fused B{B} N{N} S{S}", got, ref, "bf16")
+    # bit-identical run to run (a first version read S^T accumulators from inline asm a few cycles early on the younger wave of
+    # a SIMD: the row maximum, hence the bf16 rounding of P, moved by an ulp from launch to launch)
+    for _ in range(6):
+        again, _p = ops.xattn_fused(x.to(gpu), gamma.to(gpu), beta.to(gpu), wq.to(gpu), kv.to(gpu), wo.to(gpu), bo.to(gpu))
+        assert torch.equal(again, got)
     # the three launches: LayerNorm -> to_q, attention (short-key kernel), to_out + residual
     lnq = ops.layer_norm(x.reshape(B * N, C).to(gpu), gamma.to(gpu), beta.to(gpu), dtype="bf16")
     qq = ops.linear(lnq, wq.to(gpu), None, None, dtype="bf16").reshape(B, N, C)
