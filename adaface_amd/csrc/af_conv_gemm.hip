@@ -2801,16 +2801,17 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
   }
   // 8 x 8 maps (round 4): tiles of four whole images x 80 columns over four K slices, the images' halos resident in LDS
   // (conv3x3_s8_kernel, af_conv_s8.hip); halo_tw = 8 names it
+  // ... and the 16 x 16 maps: one whole image x 80 columns per tile, ONE K slice (256 tiles at Bf = 16)
   if (elem_size == 2 && (g_af_knobs.conv_halo8 & 2) && g_af_knobs.gemm_pp && af_conv_s8_ok(p, batch) && !p.gn_stats_out) {
     pl.tile = 5;
     pl.halo_tw = 8;
-    pl.splitk = 4;
+    pl.splitk = af_conv_s8_slices(p, batch);
   }
   const int ft = g_af_knobs.gemm_tile;
   if (ft >= 0 && ft < 4 && !(geglu && bn[ft] != 128)) pl.tile = ft;
   const int fs = g_af_knobs.gemm_splitk;
   if (fs >= 1 && batch == 1 && !geglu) pl.splitk = fs > KT ? KT : fs;
-  if (pl.halo_tw == 8 && (pl.tile != 5 || pl.splitk != 4)) pl.halo_tw = 0;   // (a forced tile / slice count: the generic kernels)
+  if (pl.halo_tw == 8 && (pl.tile != 5 || pl.splitk != af_conv_s8_slices(p, batch))) pl.halo_tw = 0;   // (a forced tile / slice count: the generic kernels)
   if (pl.splitk > 1 && pl.halo_tw != 256 && pl.halo_tw != 8) pl.halo_tw = 0;
   if (pl.halo_tw == 256 && (pl.tile != 5 || (p.Cin / 64) % pl.splitk != 0)) pl.halo_tw = 0;
   if (pl.splitk > 1) pl.ws_bytes = (size_t)pl.splitk * p.M * p.N * sizeof(float);
@@ -3085,7 +3086,7 @@ static int launch_up_phase4(ConvGemmParams p, hipStream_t stream) {
 bool af_conv_gn_stats_ok(const ConvGemmParams& p, const AfGemmPlan& pl, int cpg) {
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
   const int hn = pl.tile == 5 ? 80 : 64;
-  return g_af_knobs.gn_producer && pl.tile >= 4 && pl.splitk <= 1 && p.ks == 3 && p.stride == 1 && p.up == 0 &&
+  return g_af_knobs.gn_producer && pl.tile >= 4 && pl.splitk <= 1 && pl.halo_tw != 8 && p.ks == 3 && p.stride == 1 && p.up == 0 &&
          p.epilogue != AF_EPI_GEGLU && !p.ln_stats && !p.ln_stats_out && cpg >= 2 && cpg % 2 == 0 && hn % cpg == 0 &&
          p.N == 32 * cpg && pow2(p.Ho * p.Wo) && p.Ho * p.Wo >= 64 && p.M % 64 == 0;
 }
@@ -3262,11 +3263,13 @@ int af_launch_conv_gemm(const ConvGemmParams& p_in, int batch, hipStream_t strea
       return -1;
     }
     if (rc) return rc;
-    const long nq = (long)p.M * (p.N >> 2);
-    unsigned blocks = (unsigned)((nq + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, stream, p);
-    HIP_CHECK_RET(hipGetLastError());
+    if (p.splitk > 1) {
+      const long nq = (long)p.M * (p.N >> 2);
+      unsigned blocks = (unsigned)((nq + 255) / 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, stream, p);
+      HIP_CHECK_RET(hipGetLastError());
+    }
     return 0;
   }
   if (pl.halo_tw == 256) {

@@ -13,6 +13,11 @@
 //        seven pieces per chunk) + four weight slots of 80 x 128 B (prefetch distance three steps)
 //   K slice = Cin / 64 / 4 chunks; fp32 slabs ws[slice][M][N], reduced (+ bias, time-embedding row, residual) by the launcher's
 //   splitk_reduce_kernel, slabs summed in slice order: deterministic.
+//
+// The same kernel with ONE K slice runs the 16 x 16 maps (1280 -> 1280 x11, 2560 -> 1280 x2, 640 -> 1280 x1 per forward; M = 4096):
+// a tile is one whole image x 80 columns -- 16 x 16 = 256 tiles, so no K slices, no slabs, no reduce launch (round 3: 256 x 160
+// tiles over two slices + reduce) -- its 18 x 18 halo (324 pixels) resident per chunk; bias, time-embedding row and residual are
+// applied on the accumulators and the bf16 rows leave through a wave-private transposition tile as 16-byte stores.
 #include "af_kernels.h"
 
 #include <type_traits>
@@ -58,6 +63,7 @@ __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, const f32x4
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+template <int SPLITK_T>
 __global__ __launch_bounds__(512) void conv3x3_s8_kernel(const ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,23 +71,25 @@ __global__ __launch_bounds__(512) void conv3x3_s8_kernel(const ConvGemmParams p)
   const int ntn = p.N / BN;
   const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;   // (consecutive ids share the row tile = its halo: same XCD or not, L2 or MALL)
   const int m0 = tm * BM, n0 = tn * BN, zk = blockIdx.z;
-  const int nch = (p.Cin >> 6) / SPLITK, chunk0 = zk * nch;      // this slice's channel chunks
+  const int nch = (p.Cin >> 6) / SPLITK_T, chunk0 = zk * nch;    // this slice's channel chunks
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(reinterpret_cast<const T*>(p.src)), 0, (int)0xFFFFFFF0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(reinterpret_cast<const T*>(p.W)), 0, (int)0xFFFFFFF0u, 0x00020000);
 
   // ---- halo pieces of this wave: piece wid + 8 q covers halo slots 8 piece .. + 7 (lane >> 3 = slot, lane & 7 = 16-byte chunk);
-  // slot hp = 100 img + 10 hy + hx holds input pixel (hy - 1, hx - 1) of image (m0 / 64 + img); slots >= 400: nothing ----
+  // slot hp = HP1 img + HW hy + hx holds input pixel (hy - 1, hx - 1) of image (img0 + img); slots past the last image: nothing ----
   const int srow = lane >> 3;
   const unsigned dchunk = (unsigned)((lane & 7) ^ srow);
   const unsigned ldcb = (unsigned)p.ldc * 2u;
+  // geometry: Wo x Wo maps, Wo = 8 (four images per tile) or 16 (one); halo row pitch HW = Wo + 2, HP1 = HW^2 slots per image
+  const int wsh = p.wo_shift, Wo = 1 << wsh, HW = Wo + 2, HP1 = HW * HW, ipt = 256 >> (2 * wsh), img0 = m0 >> (2 * wsh);
   unsigned h_off[NHQ];
 #pragma unroll
   for (int q = 0; q < NHQ; ++q) {
     const int hp = (wid + 8 * q) * 8 + srow;
-    const int img = hp / 100, rem = hp - img * 100, hy = rem / 10, hx = rem - hy * 10;
+    const int img = hp / HP1, rem = hp - img * HP1, hy = rem / HW, hx = rem - hy * HW;
     const int iy = hy - 1, ix = hx - 1;
-    const bool ok = hp < 400 && (unsigned)iy < 8u && (unsigned)ix < 8u;
-    h_off[q] = ok ? (unsigned)(((m0 >> 6) + img) * 64 + iy * 8 + ix) * ldcb + dchunk * 16u : 0xFFFFFFFFu;
+    const bool ok = img < ipt && (unsigned)iy < (unsigned)Wo && (unsigned)ix < (unsigned)Wo;
+    h_off[q] = ok ? (unsigned)(((img0 + img) << (2 * wsh)) + (iy << wsh) + ix) * ldcb + dchunk * 16u : 0xFFFFFFFFu;
   }
   // weight pieces: piece wid (+ 8 for waves 0, 1) = rows 8 piece .. + 7 of the 80-row tile
   const int nwq = wid < WPIECES - 8 ? 2 : 1;
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(512) void conv3x3_s8_kernel(const ConvGemmParams p)
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
     const int t = wid * 32 + j * 16 + l15;
-    xhp[j] = (t >> 6) * 100 + ((t >> 3) & 7) * 10 + (t & 7);
+    xhp[j] = (t >> (2 * wsh)) * HP1 + ((t >> wsh) & (Wo - 1)) * HW + (t & (Wo - 1));
   }
   f32x4 acc[NI][MI];
 #pragma unroll
@@ -136,7 +144,8 @@ __global__ __launch_bounds__(512) void conv3x3_s8_kernel(const ConvGemmParams p)
       if (nwq == 2) wait_vm<2 * (D - 1) + hyoung>(); else wait_vm<(D - 1) + hyoung>();
       __builtin_amdgcn_s_barrier();
       // ---- operand addresses of this tap ----
-      constexpr int ky = tap / 3, kx = tap - 3 * ky, tapoff = ky * 10 + kx;
+      constexpr int ky = tap / 3, kx = tap - 3 * ky;
+      const int tapoff = ky * HW + kx;
       unsigned xa[MI];
 #pragma unroll
       for (int j = 0; j < MI; ++j) {
@@ -186,29 +195,97 @@ __global__ __launch_bounds__(512) void conv3x3_s8_kernel(const ConvGemmParams p)
   }
   wait_vm<0>();   // (dead pieces of the steps past the end: none may land after the workgroup has gone)
 
-  // ---- fp32 slab of this K slice: a lane holds 4 consecutive columns of one row ----
-  float* slab = reinterpret_cast<float*>(p.ws) + (long)zk * p.M * p.N;
+  if constexpr (SPLITK_T > 1) {
+    // ---- fp32 slab of this K slice: a lane holds 4 consecutive columns of one row ----
+    float* slab = reinterpret_cast<float*>(p.ws) + (long)zk * p.M * p.N;
 #pragma unroll
-  for (int j = 0; j < MI; ++j) {
-    const int m = m0 + wid * 32 + j * 16 + l15;
+    for (int j = 0; j < MI; ++j) {
+      const int m = m0 + wid * 32 + j * 16 + l15;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(slab + (long)m * p.N + n0 + i * 16 + 4 * g) = acc[i][j];
+      for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(slab + (long)m * p.N + n0 + i * 16 + 4 * g) = acc[i][j];
+    }
+  } else {
+    // ---- one K slice: bias + time-embedding row + residual on the accumulators, bf16 through a wave-private transposition tile
+    // (where the halo buffers were: every wave is past its last fragment read) into 16-byte row stores ----
+    __builtin_amdgcn_s_barrier();
+    constexpr int OPITCH = BN * 2 + 16, OCH = BN / 8, NST = 32 * OCH / 64;     // 176-byte rows, 10 chunks per row, 5 stores per lane
+    char* otile = smem + wid * (32 * OPITCH);
+    const T* res = reinterpret_cast<const T*>(p.residual);
+    const T* rowb = reinterpret_cast<const T*>(p.rowbias);
+    const int cl = 4 * g;
+    float4 bvec[NI];
+    Quad<T> bq[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      bvec[i] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0 + i * 16 + cl) : float4{0.f, 0.f, 0.f, 0.f};
+      if (rowb) bq[i].load(rowb + (long)(m0 >> p.howo_shift) * p.ldrb + n0 + i * 16 + cl);   // (a tile lies inside one sample)
+    }
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int m = m0 + wid * 32 + j * 16 + l15;
+      Quad<T> rq[NI];
+      if (res) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) rq[i].load(res + (long)m * p.ldr + n0 + i * 16 + cl);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const float* bp = reinterpret_cast<const float*>(&bvec[i]);
+        Quad<T> o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][j][e] + bp[e];
+          if (rowb) v += to_f32<T>(bq[i].e[e]);
+          if (res) v += to_f32<T>(rq[i].e[e]);
+          o.e[e] = from_f32<T>(v);
+        }
+        o.store(reinterpret_cast<T*>(otile + (j * 16 + l15) * OPITCH) + i * 16 + cl);
+      }
+    }
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(p.out), 0, (int)0xFFFFFFF0u, 0x00020000);
+    u32x4 chunk[NST];
+    unsigned orow[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const unsigned c = (unsigned)(lane + 64 * i), row = c / OCH, ch = c - row * OCH;
+      orow[i] = (unsigned)(m0 + wid * 32 + (int)row) * (unsigned)(p.ldo * 2) + ch * 16u;
+      chunk[i] = *reinterpret_cast<const u32x4*>(otile + row * OPITCH + ch * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // (all chunks and offsets first, then the stores back to back: scripts/check_isa_hazards.py)
+#pragma unroll
+    for (int i = 0; i < NST; ++i) __builtin_amdgcn_raw_buffer_store_b128(chunk[i], rs_o, orow[i], n0 * 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 }  // namespace cs8
 
-// does the eight-wave 8 x 8-map kernel take this (bf16) convolution?  It always slices K four ways.
-bool af_conv_s8_ok(const ConvGemmParams& p, int batch) {
-  return batch == 1 && !p.fp8 && p.ks == 3 && p.stride == 1 && p.pad == 1 && p.up == 0 && p.Ho == 8 && p.Wo == 8 && p.Hi == 8 && p.Wi == 8 &&
-         p.Hs == 8 && p.Ws == 8 && p.M > 0 && p.M % cs8::BM == 0 && p.N % cs8::BN == 0 && p.Cin % (64 * cs8::SPLITK) == 0 && p.K == 9 * p.Cin &&
-         p.ldc >= p.Cin && p.ldc % 8 == 0 && p.epilogue == AF_EPI_NONE && !p.ln_stats && !p.ln_stats_out && !p.gn_ab && !p.phase4 &&
-         p.src_batch_stride == (long)64 * p.ldc;
+// does the small-map kernel take this (bf16) convolution, and in how many K slices?  8 x 8 maps: 4; 16 x 16 maps: 1; 0 = no
+int af_conv_s8_slices(const ConvGemmParams& p, int batch) {
+  if (batch != 1 || p.fp8 || p.ks != 3 || p.stride != 1 || p.pad != 1 || p.up != 0 || p.Ho != p.Wo || p.Hi != p.Ho || p.Wi != p.Wo ||
+      p.Hs != p.Ho || p.Ws != p.Wo || (p.Wo != 8 && p.Wo != 16) || p.M <= 0 || p.M % cs8::BM != 0 || p.N % cs8::BN != 0 || p.K != 9 * p.Cin ||
+      p.ldc < p.Cin || p.ldc % 8 != 0 || p.epilogue != AF_EPI_NONE || p.ln_stats || p.ln_stats_out || p.gn_ab || p.phase4 ||
+      p.src_batch_stride != (long)p.Ho * p.Wo * p.ldc)
+    return 0;
+  if (p.Wo == 8) return p.Cin % (64 * cs8::SPLITK) == 0 ? cs8::SPLITK : 0;
+  return (p.Cin % 64 == 0 && p.ldo % 8 == 0 && (!p.residual || p.ldr % 4 == 0) && (!p.rowbias || p.ldrb % 4 == 0) && ((__UINTPTR_TYPE__)p.out & 15) == 0 &&
+          (long)(p.M / cs8::BM) * (p.N / cs8::BN) >= 128) ? 1 : 0;
 }
+bool af_conv_s8_ok(const ConvGemmParams& p, int batch) { return af_conv_s8_slices(p, batch) != 0; }
 int af_launch_conv_s8(const ConvGemmParams& p, hipStream_t stream) {
-  static unsigned long long attr_done = 0;
-  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&cs8::conv3x3_s8_kernel), cs8::LDS_BYTES)) return rc;
-  if (p.splitk != cs8::SPLITK || !p.ws) { af_set_error_msg("conv_s8: needs the four-slice slab workspace"); return -1; }
-  hipLaunchKernelGGL(cs8::conv3x3_s8_kernel, dim3((p.M / cs8::BM) * (p.N / cs8::BN), 1, cs8::SPLITK), dim3(512), cs8::LDS_BYTES, stream, p);
+  static unsigned long long attr_done4 = 0, attr_done1 = 0;
+  const int sl = af_conv_s8_slices(p, 1);
+  if (sl == 0 || p.splitk != sl || (sl > 1 && !p.ws) || p.wo_shift < 3 || p.howo_shift != 2 * p.wo_shift) {
+    af_set_error_msg("conv_s8: shape / slice count %d not taken by the small-map kernel", p.splitk);
+    return -1;
+  }
+  const dim3 grid((p.M / cs8::BM) * (p.N / cs8::BN), 1, sl);
+  if (sl > 1) {
+    if (int rc = af_ensure_dynamic_lds(attr_done4, reinterpret_cast<const void*>(&cs8::conv3x3_s8_kernel<cs8::SPLITK>), cs8::LDS_BYTES)) return rc;
+    hipLaunchKernelGGL(cs8::conv3x3_s8_kernel<cs8::SPLITK>, grid, dim3(512), cs8::LDS_BYTES, stream, p);
+  } else {
+    if (int rc = af_ensure_dynamic_lds(attr_done1, reinterpret_cast<const void*>(&cs8::conv3x3_s8_kernel<1>), cs8::LDS_BYTES)) return rc;
+    hipLaunchKernelGGL(cs8::conv3x3_s8_kernel<1>, grid, dim3(512), cs8::LDS_BYTES, stream, p);
+  }
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

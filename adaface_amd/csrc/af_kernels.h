@@ -48,6 +48,7 @@ int af_launch_groupnorm_fold(const void* x, long x_bs, int ldx, int B, int HW, i
 bool af_conv_gn_stats_ok(const ConvGemmParams& p, const AfGemmPlan& pl, int cpg);
 // the 8 x 8-map 3x3 convolution kernel (af_conv_s8.hip): four whole images x 80 columns per tile, always four K slices
 bool af_conv_s8_ok(const ConvGemmParams& p, int batch);
+int af_conv_s8_slices(const ConvGemmParams& p, int batch);    // K slices it runs in (8 x 8 maps: 4, 16 x 16 maps: 1), 0 = not taken
 int af_launch_conv_s8(const ConvGemmParams& p, hipStream_t stream);
 int af_conv_rowpanel_kind(const ConvGemmParams& p, int batch);   // 0 = not a row-panel launch (p.splitk as planned)
 template <typename T>
