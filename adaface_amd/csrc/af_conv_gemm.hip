@@ -2802,7 +2802,8 @@ AfGemmPlan af_plan_conv_gemm(const ConvGemmParams& p, int batch, int elem_size) 
   // 8 x 8 maps (round 4): tiles of four whole images x 80 columns over four K slices, the images' halos resident in LDS
   // (conv3x3_s8_kernel, af_conv_s8.hip); halo_tw = 8 names it
   // ... and the 16 x 16 maps: one whole image x 80 columns per tile, ONE K slice (256 tiles at Bf = 16)
-  if (elem_size == 2 && (g_af_knobs.conv_halo8 & 2) && g_af_knobs.gemm_pp && af_conv_s8_ok(p, batch) && !p.gn_stats_out) {
+  if (elem_size == 2 && (g_af_knobs.conv_halo8 & 2) && g_af_knobs.gemm_pp && af_conv_s8_ok(p, batch) && !p.gn_stats_out &&
+      (p.Wo <= 16 || (g_af_knobs.conv_halo8 & 4))) {
     pl.tile = 5;
     pl.halo_tw = 8;
     pl.splitk = af_conv_s8_slices(p, batch);

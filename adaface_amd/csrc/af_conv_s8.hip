@@ -80,16 +80,19 @@ __global__ __launch_bounds__(512) void conv3x3_s8_kernel(const ConvGemmParams p)
   const int srow = lane >> 3;
   const unsigned dchunk = (unsigned)((lane & 7) ^ srow);
   const unsigned ldcb = (unsigned)p.ldc * 2u;
-  // geometry: Wo x Wo maps, Wo = 8 (four images per tile) or 16 (one); halo row pitch HW = Wo + 2, HP1 = HW^2 slots per image
-  const int wsh = p.wo_shift, Wo = 1 << wsh, HW = Wo + 2, HP1 = HW * HW, ipt = 256 >> (2 * wsh), img0 = m0 >> (2 * wsh);
+  // geometry: a tile = 256 consecutive pixels in (image, y, x) order = `ipt` whole images of Wo x Wo (Wo = 8: four, 16: one) or R = 256 / Wo
+  // whole rows of one image (Wo = 32, 64).  Halo of one image part: (R + 2) rows x HW = Wo + 2 columns = HP1 slots
+  const int wsh = p.wo_shift, Wo = 1 << wsh, HW = Wo + 2, hwsh = p.howo_shift;
+  const int R = min(p.Ho, 256 >> wsh), HP1 = (R + 2) * HW, ipt = 256 / (R << wsh);
+  const int img0 = m0 >> hwsh, y0 = (m0 & ((1 << hwsh) - 1)) >> wsh;
   unsigned h_off[NHQ];
 #pragma unroll
   for (int q = 0; q < NHQ; ++q) {
     const int hp = (wid + 8 * q) * 8 + srow;
     const int img = hp / HP1, rem = hp - img * HP1, hy = rem / HW, hx = rem - hy * HW;
-    const int iy = hy - 1, ix = hx - 1;
-    const bool ok = img < ipt && (unsigned)iy < (unsigned)Wo && (unsigned)ix < (unsigned)Wo;
-    h_off[q] = ok ? (unsigned)(((img0 + img) << (2 * wsh)) + (iy << wsh) + ix) * ldcb + dchunk * 16u : 0xFFFFFFFFu;
+    const int iy = y0 + hy - 1, ix = hx - 1;
+    const bool ok = img < ipt && (unsigned)iy < (unsigned)p.Ho && (unsigned)ix < (unsigned)Wo;
+    h_off[q] = ok ? (unsigned)(((img0 + img) << hwsh) + (iy << wsh) + ix) * ldcb + dchunk * 16u : 0xFFFFFFFFu;
   }
   // weight pieces: piece wid (+ 8 for waves 0, 1) = rows 8 piece .. + 7 of the 80-row tile
   const int nwq = wid < WPIECES - 8 ? 2 : 1;
@@ -120,7 +123,8 @@ __global__ __launch_bounds__(512) void conv3x3_s8_kernel(const ConvGemmParams p)
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
     const int t = wid * 32 + j * 16 + l15;
-    xhp[j] = (t >> (2 * wsh)) * HP1 + ((t >> wsh) & (Wo - 1)) * HW + (t & (Wo - 1));
+    const int part = t / (R << wsh), yl = (t >> wsh) - part * R;
+    xhp[j] = part * HP1 + yl * HW + (t & (Wo - 1));
   }
   f32x4 acc[NI][MI];
 #pragma unroll
@@ -133,10 +137,20 @@ __global__ __launch_bounds__(512) void conv3x3_s8_kernel(const ConvGemmParams p)
 #pragma unroll
   for (int s = 0; s < D; ++s) stage_w(s, s);
 
+  // Software pipeline over the tap steps: the MFMAs of the last two weight blocks of a step (8 of its 20) are HELD BACK and
+  // issued behind the next step's barrier, while that step's first fragment reads are in flight -- a wave otherwise sits out the
+  // LDS latency after every barrier with nothing to give the matrix pipe.  Two register sets (activation fragments + the
+  // two held weight blocks) alternate with the tap's parity; nine taps per chunk: one copy of the set per chunk.
+  u32x4 xs[2][MI][2], wh[2][2][2];
+#pragma unroll
+  for (int j = 0; j < MI; ++j) xs[1][j][0] = xs[1][j][1] = u32x4{0u, 0u, 0u, 0u};     // (the first step multiplies zeros)
+#pragma unroll
+  for (int b2 = 0; b2 < 2; ++b2) wh[1][b2][0] = wh[1][b2][1] = u32x4{0u, 0u, 0u, 0u};
   int hb = 0, slot = 0;
   for (int c = 0; c < nch; ++c) {
     static_for<0, 9>([&](auto tc) {
       constexpr int tap = decltype(tc)::value;
+      constexpr int cs = tap & 1, ps = cs ^ 1;      // this step's register set / the previous step's
       // vmcnt: the weights of this step and (tap 0) every halo piece of this chunk have landed.  Younger than this step's
       // weights: the weights of the next D - 1 steps and the halo pieces the last three steps issued behind their weights
       // (taps 0-6 issue one each; tap 0 itself needs the one tap 6 issued: counted out)
@@ -154,45 +168,79 @@ __global__ __launch_bounds__(512) void conv3x3_s8_kernel(const ConvGemmParams p)
       }
       const unsigned wa0 = lds0 + (unsigned)(W_BASE + slot * WBYTES) + w_base + fch0;
       const unsigned wa1 = lds0 + (unsigned)(W_BASE + slot * WBYTES) + w_base + fch1;
-      u32x4 xf[MI][2], wf[NI][2];
+      u32x4 wf[3][2];
 #pragma unroll
       for (int j = 0; j < MI; ++j) {
-        xf[j][0] = lds_read128(xa[j]);
-        xf[j][1] = lds_read128(xa[j] ^ 64u);
+        xs[cs][j][0] = lds_read128(xa[j]);
+        xs[cs][j][1] = lds_read128(xa[j] ^ 64u);
       }
-      auto rd = [&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        wf[i][0] = lds_read128o<i * 2048>(wa0);
-        wf[i][1] = lds_read128o<i * 2048>(wa1);
-      };
-      rd(std::integral_constant<int, 0>{});
-      rd(std::integral_constant<int, 1>{});
-      rd(std::integral_constant<int, 2>{});
-      wait_lgkm4<6>(xf[0][0], xf[0][1], xf[1][0], xf[1][1]);
+      wf[0][0] = lds_read128o<0 * 2048>(wa0); wf[0][1] = lds_read128o<0 * 2048>(wa1);
+      wf[1][0] = lds_read128o<1 * 2048>(wa0); wf[1][1] = lds_read128o<1 * 2048>(wa1);
+      wf[2][0] = lds_read128o<2 * 2048>(wa0); wf[2][1] = lds_read128o<2 * 2048>(wa1);
       __builtin_amdgcn_sched_barrier(0);
-      static_for<0, NI>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        constexpr int issued = (i + 3) < NI ? (i + 3) : NI;
-        wait_lgkm2<2 * (issued - i - 1)>(wf[i][0], wf[i][1]);
+      // ---- the previous step's blocks 3, 4 (registers only) ----
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2)
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
-          acc[i][j] = mma(wf[i][0], xf[j][0], acc[i][j]);
-          acc[i][j] = mma(wf[i][1], xf[j][1], acc[i][j]);
-          asm volatile("" : "+v"(acc[i][j]));
+          acc[3 + b2][j] = mma(wh[ps][b2][0], xs[ps][j][0], acc[3 + b2][j]);
+          acc[3 + b2][j] = mma(wh[ps][b2][1], xs[ps][j][1], acc[3 + b2][j]);
+          asm volatile("" : "+v"(acc[3 + b2][j]));
         }
-        if constexpr (i + 3 < NI) rd(std::integral_constant<int, i + 3>{});
-        if constexpr (i == 1) {
-          // the slot the previous step left: weights of step + D; then (taps 0-6) one halo piece of the next chunk
-          stage_w(c * 9 + tap + D, (slot + D) & (NS - 1));
-          if constexpr (tap < NHQ) stage_h(std::integral_constant<int, tap>{}, hb ^ 1, c + 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- blocks 0, 1, 2 of this step; blocks 3, 4 are read for the next one ----
+      wait_lgkm4<4>(xs[cs][0][0], xs[cs][0][1], xs[cs][1][0], xs[cs][1][1]);
+      wait_lgkm2<4>(wf[0][0], wf[0][1]);
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        acc[0][j] = mma(wf[0][0], xs[cs][j][0], acc[0][j]);
+        acc[0][j] = mma(wf[0][1], xs[cs][j][1], acc[0][j]);
+        asm volatile("" : "+v"(acc[0][j]));
+      }
+      wh[cs][0][0] = lds_read128o<3 * 2048>(wa0); wh[cs][0][1] = lds_read128o<3 * 2048>(wa1);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lgkm2<4>(wf[1][0], wf[1][1]);
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        acc[1][j] = mma(wf[1][0], xs[cs][j][0], acc[1][j]);
+        acc[1][j] = mma(wf[1][1], xs[cs][j][1], acc[1][j]);
+        asm volatile("" : "+v"(acc[1][j]));
+      }
+      // the slot the previous step left: weights of step + D; then (taps 0-6) one halo piece of the next chunk
+      stage_w(c * 9 + tap + D, (slot + D) & (NS - 1));
+      if constexpr (tap < NHQ) stage_h(std::integral_constant<int, tap>{}, hb ^ 1, c + 1);
+      wh[cs][1][0] = lds_read128o<4 * 2048>(wa0); wh[cs][1][1] = lds_read128o<4 * 2048>(wa1);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lgkm2<4>(wf[2][0], wf[2][1]);
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        acc[2][j] = mma(wf[2][0], xs[cs][j][0], acc[2][j]);
+        acc[2][j] = mma(wf[2][1], xs[cs][j][1], acc[2][j]);
+        asm volatile("" : "+v"(acc[2][j]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // every read of this step's slot is back before the wave reaches the next barrier (the slot is restaged behind it)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(wh[cs][0][0]), "+v"(wh[cs][0][1]), "+v"(wh[cs][1][0]), "+v"(wh[cs][1][1])
+                   :
+                   : "memory");
       slot = (slot + 1) & (NS - 1);
     });
+    // tap 8 left its fragments in set 0; tap 0 of the next chunk looks for them in set 1
+#pragma unroll
+    for (int j = 0; j < MI; ++j) { xs[1][j][0] = xs[0][j][0]; xs[1][j][1] = xs[0][j][1]; }
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) { wh[1][b2][0] = wh[0][b2][0]; wh[1][b2][1] = wh[0][b2][1]; }
     hb ^= 1;
   }
+  // the last step's held-back blocks
+#pragma unroll
+  for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      acc[3 + b2][j] = mma(wh[1][b2][0], xs[1][j][0], acc[3 + b2][j]);
+      acc[3 + b2][j] = mma(wh[1][b2][1], xs[1][j][1], acc[3 + b2][j]);
+    }
   wait_vm<0>();   // (dead pieces of the steps past the end: none may land after the workgroup has gone)
 
   if constexpr (SPLITK_T > 1) {
@@ -261,12 +309,16 @@ __global__ __launch_bounds__(512) void conv3x3_s8_kernel(const ConvGemmParams p)
 
 // does the small-map kernel take this (bf16) convolution, and in how many K slices?  8 x 8 maps: 4; 16 x 16 maps: 1; 0 = no
 int af_conv_s8_slices(const ConvGemmParams& p, int batch) {
-  if (batch != 1 || p.fp8 || p.ks != 3 || p.stride != 1 || p.pad != 1 || p.up != 0 || p.Ho != p.Wo || p.Hi != p.Ho || p.Wi != p.Wo ||
-      p.Hs != p.Ho || p.Ws != p.Wo || (p.Wo != 8 && p.Wo != 16) || p.M <= 0 || p.M % cs8::BM != 0 || p.N % cs8::BN != 0 || p.K != 9 * p.Cin ||
-      p.ldc < p.Cin || p.ldc % 8 != 0 || p.epilogue != AF_EPI_NONE || p.ln_stats || p.ln_stats_out || p.gn_ab || p.phase4 ||
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  if (batch != 1 || p.fp8 || p.ks != 3 || p.stride != 1 || p.pad != 1 || p.up != 0 || p.Hi != p.Ho || p.Wi != p.Wo ||
+      p.Hs != p.Ho || p.Ws != p.Wo || !pow2(p.Wo) || !pow2(p.Ho) || p.Wo < 8 || p.Wo > 64 || p.M <= 0 || p.M % cs8::BM != 0 || p.N % cs8::BN != 0 ||
+      p.K != 9 * p.Cin || p.ldc < p.Cin || p.ldc % 8 != 0 || p.epilogue != AF_EPI_NONE || p.ln_stats || p.ln_stats_out || p.gn_ab || p.phase4 ||
       p.src_batch_stride != (long)p.Ho * p.Wo * p.ldc)
     return 0;
-  if (p.Wo == 8) return p.Cin % (64 * cs8::SPLITK) == 0 ? cs8::SPLITK : 0;
+  // the tile's halo must fit the buffer: whole images (Ho * Wo <= 256) or 256 / Wo whole rows of one image
+  const int R = p.Ho < 256 / p.Wo ? p.Ho : 256 / p.Wo;
+  if (256 % (R * p.Wo) != 0 || (256 / (R * p.Wo)) * (R + 2) * (p.Wo + 2) > cs8::HSLOTS || (p.Ho * p.Wo > 256 && p.Ho % R != 0)) return 0;
+  if (p.Wo == 8 && p.Ho == 8) return p.Cin % (64 * cs8::SPLITK) == 0 ? cs8::SPLITK : 0;
   return (p.Cin % 64 == 0 && p.ldo % 8 == 0 && (!p.residual || p.ldr % 4 == 0) && (!p.rowbias || p.ldrb % 4 == 0) && ((__UINTPTR_TYPE__)p.out & 15) == 0 &&
           (long)(p.M / cs8::BM) * (p.N / cs8::BN) >= 128) ? 1 : 0;
 }
@@ -274,7 +326,7 @@ bool af_conv_s8_ok(const ConvGemmParams& p, int batch) { return af_conv_s8_slice
 int af_launch_conv_s8(const ConvGemmParams& p, hipStream_t stream) {
   static unsigned long long attr_done4 = 0, attr_done1 = 0;
   const int sl = af_conv_s8_slices(p, 1);
-  if (sl == 0 || p.splitk != sl || (sl > 1 && !p.ws) || p.wo_shift < 3 || p.howo_shift != 2 * p.wo_shift) {
+  if (sl == 0 || p.splitk != sl || (sl > 1 && !p.ws) || p.wo_shift < 3 || p.howo_shift < p.wo_shift) {
     af_set_error_msg("conv_s8: shape / slice count %d not taken by the small-map kernel", p.splitk);
     return -1;
   }
