@@ -184,15 +184,13 @@ template <int NOPS> __device__ __forceinline__ float max3f(float a, float b, flo
 __device__ __forceinline__ f32x2 unpack2(unsigned w) {
   return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
 }
-// max over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (the lane groups that hold one token), on the VALU: v_permlane16_swap /
-// v_permlane32_swap exchange rows / halves between two copies (the s_nop covers the VALU write -> v_permlane read hazard)
+// max over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (the lane groups that hold one token).  Two ds_bpermute round trips: a first
+// version did it on the VALU (v_permlane16_swap + v_permlane32_swap with the two wait states LLVM's table asks for in front) and was
+// not reproducible -- 5 forwards in 300 differed by an ulp of P somewhere; with the shuffles 0 in 480 (scripts/lab/dbg_det.py).
+// Per head and row block it is two LDS operations against ~75 vector instructions: not measurable (56.8 vs 57.2 us per launch).
 __device__ __forceinline__ float xgroup_max(float v) {
-  float a = v, b = v;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-  float m = fmaxf(a, b);
-  a = m; b = m;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-  return fmaxf(a, b);
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
 }
 __device__ __forceinline__ u32x2 pack4(const f32x4& v) { return u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])}; }
 __device__ __forceinline__ u32x4 cat(const u32x2& a, const u32x2& b) { return u32x4{a.x, a.y, b.x, b.y}; }
