@@ -44,7 +44,7 @@ PEAK_BF16 = 2.5e15      # dense bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_F32 = 157.3e12
 PEAK_MXFP8 = 5.0e15     # dense block-scaled fp8 MFMA peak (the fp8 convolutions' own roofline)
 # af_prof classes (include/adaface_hip.h)
-K_NAMES = ["conv_gemm_other", "attention", "groupnorm", "layernorm", "other", "conv_gemm_pp<160,gather>",
+K_NAMES = ["conv_gemm_other", "attention (+ the fused cross-attention layers)", "groupnorm", "layernorm", "other", "conv_gemm_pp<160,gather> + conv3x3_s8",
            "conv_gemm_pp<160,plain>", "conv_gemm_pp<128>", "conv_gemm_pp<fp8>", "conv3x3_halo8"]
 GEMM_CLASSES = (0, 5, 6, 7, 8, 9)
 DOMINANT = 9            # conv3x3_halo8_kernel: the 3x3 / stride-1 convolutions, the largest single kernel of a bf16 step
