@@ -1689,6 +1689,19 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
       const_cast<T*>(reinterpret_cast<const T*>(p.W)), 0, (int)0xFFFFFFF0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(p.out), 0, (int)0xFFFFFFF0u, 0x00020000);
 
+  // ---- the bias (and, LayerNorm consumer, the column sums) of this workgroup's columns -> LDS, once.  Fetched from memory in
+  // every tile's epilogue they were the YOUNGEST vector-memory operations of the wave: waiting for them waits for every LDS-DMA
+  // piece of the D steps in flight in front of them (vmcnt counts in order) -- one memory latency per column tile with nothing
+  // to compute (round 4: 20 tiles per workgroup in the GEGLU forms) ----
+  float* vecs = reinterpret_cast<float*>(smem + C::LDS_BYTES);
+  const int nvcol = ntn * C::BN;                    // columns of this workgroup
+  for (int c4 = tid; c4 < nvcol / 4; c4 += 512) {
+    const int col = nt_begin * C::BN + 4 * c4;
+    *reinterpret_cast<float4*>(vecs + 4 * c4) = p.bias ? *reinterpret_cast<const float4*>(p.bias + col) : float4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (LNMODE == 1) *reinterpret_cast<float4*>(vecs + nvcol + 4 * c4) = *reinterpret_cast<const float4*>(p.ln_colsum + col);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (visible to the other waves behind the first step's barrier)
+
   // ---- the wave's 32 activation rows as MFMA B fragments: block j, K chunk kc, half u -> k = 64 kc + 32 u + 8 (lane >> 4) ----
   pp_u32x4 xr[MJ][KC][2];
   // store mapping: chunk c = lane + 64 i of the wave's 32 x CPR chunks -> row c / CPR, 16-byte chunk c % CPR of its segment
@@ -1864,10 +1877,21 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
     const int ncol = nt * C::OCOLS;                // first output column of the tile
     if constexpr (GEGLU) {
       float4 bvec[NIW], cvec[LNMODE == 1 ? NIW : 1];
+      {
+        const unsigned va = lds0 + (unsigned)C::LDS_BYTES + (unsigned)((ntl * C::BN + cl) * 4);
+        pp_u32x4 tb[NIW], tc[LNMODE == 1 ? NIW : 1];
+        pp_static_for<0, NIW>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          tb[i] = pp_lds_read128<i * 64>(va);
+          if constexpr (LNMODE == 1) tc[i] = pp_lds_read128<i * 64>(va + (unsigned)nvcol * 4u);
+        });
+        pp_wait_lgkm0();
 #pragma unroll
-      for (int i = 0; i < NIW; ++i) {
-        bvec[i] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nt * C::BN + i * 16 + cl) : float4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (LNMODE == 1) cvec[i] = *reinterpret_cast<const float4*>(p.ln_colsum + nt * C::BN + i * 16 + cl);
+        for (int i = 0; i < NIW; ++i) {
+          asm volatile("" : "+v"(tb[i]));
+          bvec[i] = __builtin_bit_cast(float4, tb[i]);
+          if constexpr (LNMODE == 1) { asm volatile("" : "+v"(tc[i])); cvec[i] = __builtin_bit_cast(float4, tc[i]); }
+        }
       }
 #pragma unroll
       for (int k2 = 0; k2 < NIW / 2; ++k2) {
@@ -1909,11 +1933,21 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         float4 bvec[NH], cvec[LNMODE == 1 ? NH : 1];
+        {
+          const unsigned va = lds0 + (unsigned)C::LDS_BYTES + (unsigned)((ntl * C::BN + hh * NH * 16 + cl) * 4);
+          pp_u32x4 tb[NH], tc[LNMODE == 1 ? NH : 1];
+          pp_static_for<0, NH>([&](auto ic) {
+            constexpr int ii = decltype(ic)::value;
+            tb[ii] = pp_lds_read128<ii * 64>(va);
+            if constexpr (LNMODE == 1) tc[ii] = pp_lds_read128<ii * 64>(va + (unsigned)nvcol * 4u);
+          });
+          pp_wait_lgkm0();
 #pragma unroll
-        for (int ii = 0; ii < NH; ++ii) {
-          const int i = hh * NH + ii;
-          bvec[ii] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nt * C::BN + i * 16 + cl) : float4{0.f, 0.f, 0.f, 0.f};
-          if constexpr (LNMODE == 1) cvec[ii] = *reinterpret_cast<const float4*>(p.ln_colsum + nt * C::BN + i * 16 + cl);
+          for (int ii = 0; ii < NH; ++ii) {
+            asm volatile("" : "+v"(tb[ii]));
+            bvec[ii] = __builtin_bit_cast(float4, tb[ii]);
+            if constexpr (LNMODE == 1) { asm volatile("" : "+v"(tc[ii])); cvec[ii] = __builtin_bit_cast(float4, tc[ii]); }
+          }
         }
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
@@ -1983,12 +2017,15 @@ template <bool GEGLU, int LNMODE, bool RES, int KC, int MJ, int D>
 static int launch_rowpanel_depth(const ConvGemmParams& p, hipStream_t stream) {
   using C = RowPanelCfgT<GEGLU, KC, MJ, D>;
   static unsigned long long attr_done = 0;
-  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&rowpanel_kernel<GEGLU, LNMODE, RES, KC, MJ, D>), C::LDS_BYTES)) return rc;
+  if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&rowpanel_kernel<GEGLU, LNMODE, RES, KC, MJ, D>), 160 * 1024)) return rc;
   const int panels = (p.M + C::BM - 1) / C::BM, ntn = p.N / C::BN;
   int ny = 1;                                       // column tiles of a panel over ny workgroups until ~256 exist
   while (panels * ny < 192 && ny * 2 <= ntn && ntn % (ny * 2) == 0) ny *= 2;
+  // behind the ring and the transposition tiles: the bias (+ column sums) of a workgroup's columns, fp32
+  const int lds_bytes = C::LDS_BYTES + (LNMODE == 1 ? 2 : 1) * ((ntn + ny - 1) / ny) * C::BN * 4;
+  if (lds_bytes > 160 * 1024) { af_set_error_msg("row-panel GEMM: N = %d does not leave room for its bias vectors in LDS", p.N); return -1; }
   dim3 grid(panels, ny, 1);
-  hipLaunchKernelGGL((rowpanel_kernel<GEGLU, LNMODE, RES, KC, MJ, D>), grid, dim3(512), C::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((rowpanel_kernel<GEGLU, LNMODE, RES, KC, MJ, D>), grid, dim3(512), lds_bytes, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
