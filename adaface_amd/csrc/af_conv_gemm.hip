@@ -1694,13 +1694,18 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
   // piece of the D steps in flight in front of them (vmcnt counts in order) -- one memory latency per column tile with nothing
   // to compute (round 4: 20 tiles per workgroup in the GEGLU forms) ----
   float* vecs = reinterpret_cast<float*>(smem + C::LDS_BYTES);
-  const int nvcol = ntn * C::BN;                    // columns of this workgroup
-  for (int c4 = tid; c4 < nvcol / 4; c4 += 512) {
+  const int nvcol = ntn * C::BN;                    // columns of this workgroup (<= 6144: three float4 per thread and vector)
+  float4 vb[3], vc[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {                     // (issued here, written to LDS behind the row loads below: one memory round trip)
+    const int c4 = tid + 512 * r;
     const int col = nt_begin * C::BN + 4 * c4;
-    *reinterpret_cast<float4*>(vecs + 4 * c4) = p.bias ? *reinterpret_cast<const float4*>(p.bias + col) : float4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (LNMODE == 1) *reinterpret_cast<float4*>(vecs + nvcol + 4 * c4) = *reinterpret_cast<const float4*>(p.ln_colsum + col);
+    vb[r] = vc[r] = float4{0.f, 0.f, 0.f, 0.f};
+    if (c4 < nvcol / 4) {
+      if (p.bias) vb[r] = *reinterpret_cast<const float4*>(p.bias + col);
+      if constexpr (LNMODE == 1) vc[r] = *reinterpret_cast<const float4*>(p.ln_colsum + col);
+    }
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (visible to the other waves behind the first step's barrier)
 
   // ---- the wave's 32 activation rows as MFMA B fragments: block j, K chunk kc, half u -> k = 64 kc + 32 u + 8 (lane >> 4) ----
   pp_u32x4 xr[MJ][KC][2];
@@ -1745,6 +1750,16 @@ __global__ __launch_bounds__(512) void rowpanel_kernel(const ConvGemmParams p) {
       ln_rs[j] = st.y;
     }
   }
+
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int c4 = tid + 512 * r;
+    if (c4 < nvcol / 4) {
+      *reinterpret_cast<float4*>(vecs + 4 * c4) = vb[r];
+      if constexpr (LNMODE == 1) *reinterpret_cast<float4*>(vecs + nvcol + 4 * c4) = vc[r];
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (visible to the other waves behind the first step's barrier)
 
   if (p.gn_ab) {
     // GroupNorm of the consumer's input (see ConvGemmParams::gn_ab), after every row load of the wave has been issued: the
@@ -2023,7 +2038,7 @@ static int launch_rowpanel_depth(const ConvGemmParams& p, hipStream_t stream) {
   while (panels * ny < 192 && ny * 2 <= ntn && ntn % (ny * 2) == 0) ny *= 2;
   // behind the ring and the transposition tiles: the bias (+ column sums) of a workgroup's columns, fp32
   const int lds_bytes = C::LDS_BYTES + (LNMODE == 1 ? 2 : 1) * ((ntn + ny - 1) / ny) * C::BN * 4;
-  if (lds_bytes > 160 * 1024) { af_set_error_msg("row-panel GEMM: N = %d does not leave room for its bias vectors in LDS", p.N); return -1; }
+  if (lds_bytes > 160 * 1024 || ((ntn + ny - 1) / ny) * C::BN > 6144) { af_set_error_msg("row-panel GEMM: N = %d does not leave room for its bias vectors in LDS", p.N); return -1; }
   dim3 grid(panels, ny, 1);
   hipLaunchKernelGGL((rowpanel_kernel<GEGLU, LNMODE, RES, KC, MJ, D>), grid, dim3(512), lds_bytes, stream, p);
   HIP_CHECK_RET(hipGetLastError());
