@@ -27,6 +27,7 @@
 //     32-row blocks; HBM traffic is exactly the unpadded Q, K, V, O.
 #include "af_common.h"
 #include <math.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -407,15 +408,30 @@ template <typename T, int DH> __device__ __forceinline__ void attn_body(const At
 //     loop of the kernel above.  tests/test_ops_gpu.py::test_attention_spiky_bf16_dh40 forces both paths.
 // Measured (MI355X, lab, same random data, one process): 487-517 us -> 391-412 us for N = S = 4096, B = 16, H = 8.
 // ---------------------------------------------------------------------------------------------------------------
-namespace ring40 {
-constexpr int DH = 40, FS = 3, DB = 2, WAVES = 8, NT = WAVES * 64;
-constexpr int KROW = 112, VROW = 128;
-constexpr int K_BYTES = 64 * KROW, V_BYTES = 64 * VROW, BUF = K_BYTES + V_BYTES;   // 7168 + 8192
-constexpr int KP = K_BYTES / 1024, VP = V_BYTES / 1024, NPIECE = KP + VP;          // 7 + 8 pieces of 1 KiB
-constexpr int PPW = (NPIECE + WAVES - 1) / WAVES;                                  // 2 (wave 7: 1)
+namespace ring {
 constexpr int NBUF = 2;
-constexpr int LDS_BYTES = NBUF * BUF;
-constexpr int MREF_STEP = 2, MREF_HALF = 1, MREF_ELEM = 0;   // d = 40 -> byte 80: step 2 (64..95), half 1, element 0
+// DH = 40: the layout described above.  DH = 80 (round 4: the 32x32-level self-attention, N = S = 1024) is the same kernel
+// with 10 data chunks per row: K rows of 11 chunks (176 B: 32 rows x 44 dwords are conflict-free for ds_read_b128; the
+// sixth k step's upper half would be chunk 11 -- its Q half is zero, so those lanes read the m_ref chunk again), V rows of
+// 12 chunks = three 64-byte d blocks (192 B: the four rows a ds_read_b64_tr_b16 half touches start at banks 0 / 48 / 32 /
+// 16 -- no swap needed), 23 pieces per tile, three O^T blocks, 24 MFMAs per wave and tile; ~165 VGPRs: four-wave workgroups
+// (W_ = 4: 128 queries share a staged tile), three per CU.
+template <int DH_, int W_ = 8> struct Cfg {
+  static constexpr int DH = DH_, NCH = DH / 8, WAVES = W_, NT = 64 * W_;   // W_ waves = 32 W_ queries share each staged tile                  // 16-byte data chunks per row
+  static constexpr int FS = (DH + 1 + 15) / 16;                 // 16-wide k steps of QK^T, the m_ref slot included
+  static constexpr int DB = (DH + 1 + 31) / 32;                 // 32-row blocks of O^T, the ones row included
+  static constexpr int KCH = DH == 40 ? 7 : 11, VCH = 4 * DB;   // chunks per staged K / V row
+  static constexpr int KROW = 16 * KCH, VROW = 16 * VCH;
+  static constexpr int K_BYTES = 64 * KROW, V_BYTES = 64 * VROW, BUF = K_BYTES + V_BYTES;
+  static constexpr int KP = KCH, VP = VCH, NPIECE = KP + VP;    // pieces of 1 KiB
+  static constexpr int PPW = (NPIECE + WAVES - 1) / WAVES;
+  static constexpr int LDS_BYTES = NBUF * BUF;    // dh 80: the pipelined pass keeps a three-deep ring
+  static constexpr int MREF_STEP = DH / 16, MREF_HALF = (DH % 16) / 8, MREF_ELEM = 0;   // d = DH
+  static constexpr bool VSWZ = VROW == 128;                     // 128-byte V rows: the halves of odd row pairs are swapped
+  static constexpr bool KLASTFIX = 2 * (FS - 1) + 1 >= KCH;     // the last k step's upper half lies beyond the row
+  static constexpr int KPADS = KCH - NCH, VPADS = VCH - NCH, PADS = 64 * (KPADS + VPADS);
+  static_assert(DH % 8 == 0 && KCH > NCH && VCH > NCH && 2 * (FS - 1) < KCH, "row layout");
+};
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // (HIP's uint4 / uint2 are structs: asm operands must be vectors)
 
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_base, unsigned voffset, unsigned soffset) {
@@ -439,15 +455,45 @@ template <int N> __device__ __forceinline__ void wait_lgkm2(u32x2& a, u32x2& b) 
 __device__ __forceinline__ void mma(const u32x4& a, const uint4& b, f32x16& c) {
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// workgroup -> (query block, head, sample).  Workgroups go to the XCDs round-robin in launch order; mapped plainly, the query
+// blocks of one head land on eight different XCDs and each XCD's L2 fetches that head's K / V for itself.  Here consecutive
+// SLOTS of one XCD are the query blocks of one head: they run together on one L2 (heads x samples must divide by 8, else plain).
+__device__ __forceinline__ void ring_coords(int& qb, int& head, int& b) {
+  const int nqb = gridDim.x, H = gridDim.y, HB = gridDim.y * gridDim.z;
+  if (HB & 7) { qb = blockIdx.x; head = blockIdx.y; b = blockIdx.z; return; }
+  const int id = blockIdx.x + nqb * (blockIdx.y + H * blockIdx.z);
+  const int xcd = id & 7, slot = id >> 3;
+  const int grp = slot / nqb;
+  qb = slot - grp * nqb;
+  const int yz = grp * 8 + xcd;
+  b = yz / H;
+  head = yz - b * H;
+}
+template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, N>(f);
+  }
+}
 
 // one pass over the keys for this workgroup's 256 queries.  RUNMAX = false: reference from the first tile only;
 // returns whether this lane saw a non-finite result (outputs are written either way; a repeat overwrites them).
-template <bool RUNMAX> __device__ __forceinline__ bool pass(const AttnParams& p, char* smem) {
+// MODE 0: softmax reference from the first tile only (RUNMAX = false above); 1: the running bf16 reference (the repeat);
+// 2: the plain online softmax -- fp32 running row maximum, exp2(s - m), O rescaled when it moves -- with no m_ref slot in the
+// contraction (one k step fewer when DH is a multiple of 16): operation for operation what attn_body does for dh 80, so the
+// ring kernel is BIT-IDENTICAL to the four-wave kernel it replaces there (test_attention_dh80_ring_bit_identical).
+template <int DH, int MODE, int W = 8> __device__ __forceinline__ bool pass(const AttnParams& p, char* smem) {
   typedef bf16 T;
+  using C = Cfg<DH, W>;
+  constexpr int WAVES = W, NT = 64 * W;
+  constexpr bool RUNMAX = MODE == 1, EXACT = MODE == 2;
+  constexpr int FS = EXACT ? (DH + 15) / 16 : C::FS, DB = C::DB, KROW = C::KROW, VROW = C::VROW, K_BYTES = C::K_BYTES, BUF = C::BUF, KP = C::KP,
+                NPIECE = C::NPIECE, PPW = C::PPW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q = blockIdx.x * (WAVES * 32) + wave * 32 + l31;
+  int qb, head, b;
+  ring_coords(qb, head, b);
+  const int q = qb * (WAVES * 32) + wave * 32 + l31;
   const bool q_ok = q < p.Nq;
   const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * p.bsq + head * DH;
   const T* K = reinterpret_cast<const T*>(p.k) + (long)b * p.bsk + head * DH;
@@ -456,33 +502,23 @@ template <bool RUNMAX> __device__ __forceinline__ bool pass(const AttnParams& p,
   const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(K), 0, (p.Nk - 1) * p.ldk * 2 + DH * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(V), 0, (p.Nk - 1) * p.ldv * 2 + DH * 2, 0x00020000);
 
-  // Q fragments (B operand of S^T = K Q^T), pre-multiplied by scale*log2(e): the wave's OLDEST vector-memory operations
   const float sl2 = p.scale * 1.44269504088896340736f;
   uint4 qf[FS];
-#pragma unroll
-  for (int s = 0; s < FS; ++s) {
-    const int d0 = (32 * s + 16 * h) / 2;
-    Vec16<T> v;
-    v.u = make_uint4(0, 0, 0, 0);
-    if (q_ok && d0 < DH) v.u = *reinterpret_cast<const uint4*>(Q + (long)q * p.ldq + d0);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v.e[e] = from_f32<T>(to_f32<T>(v.e[e]) * sl2);
-    qf[s] = v.u;
-  }
-  // ---- DMA pieces of this wave: piece = wave + 8 j; pieces 0..6 = K image, 7..14 = V image.  Lane -> (row, chunk) of
-  // the image; chunk >= 5 = pad (lane masked off) ----
+  // ---- DMA pieces of this wave: piece = wave + 8 j; pieces 0..KP-1 = K image, the rest = V image.  Lane -> (row, chunk) of
+  // the image; chunk >= NCH = pad (lane masked off) ----
   unsigned voff[PPW];
   bool act[PPW];
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
     const int piece = wave + WAVES * j;
     if (piece < KP) {
-      const int g = piece * 64 + lane, row = g / 7, c = g - row * 7;
-      act[j] = c < 5;
+      const int g = piece * 64 + lane, row = g / C::KCH, c = g - row * C::KCH;
+      act[j] = c < C::NCH;
       voff[j] = (unsigned)(row * p.ldk * 2 + c * 16);
     } else {
-      const int g = (piece - KP) * 64 + lane, row = g >> 3, c = (g & 7) ^ (((row >> 1) & 1) << 2);
-      act[j] = c < 5 && piece < NPIECE;
+      const int g = (piece - KP) * 64 + lane, row = g / C::VCH, pos = g - row * C::VCH;
+      const int c = C::VSWZ ? pos ^ (((row >> 1) & 1) << 2) : pos;
+      act[j] = c < C::NCH && piece < NPIECE;
       voff[j] = (unsigned)(row * p.ldv * 2 + c * 16);
     }
   }
@@ -500,17 +536,26 @@ template <bool RUNMAX> __device__ __forceinline__ bool pass(const AttnParams& p,
   };
   const int nt = (p.Nk + 63) / 64;
   stage(0, 0);
-  // pads of both buffers (disjoint from everything the DMA writes; never written again)
-  for (int idx = tid; idx < NBUF * 320; idx += NT) {
-    const int bufi = idx / 320, r = idx - bufi * 320;
+  // Q fragments (B operand of S^T = K Q^T), loaded BEHIND the first tile's LDS-DMA so that the two latencies overlap (round 4;
+  // before, Q was loaded and scaled ahead of the staging); pre-multiplied by scale*log2(e) after the wait below
+#pragma unroll
+  for (int s = 0; s < FS; ++s) {
+    const int d0 = (32 * s + 16 * h) / 2;
+    qf[s] = make_uint4(0, 0, 0, 0);
+    if (q_ok && d0 < DH) qf[s] = *reinterpret_cast<const uint4*>(Q + (long)q * p.ldq + d0);
+  }
+  // pads of both buffers (disjoint from everything the DMA writes; never written again): chunk NCH of a K row = [1.0, 0 x7]
+  // (the K side of the -m_ref slot), of a V row the ones column; the chunks behind them zeros
+  for (int idx = tid; idx < NBUF * C::PADS; idx += NT) {
+    const int bufi = idx / C::PADS, r = idx - bufi * C::PADS;
     char* base = smem + bufi * BUF;
-    if (r < 128) {
-      const int row = r >> 1, c = 5 + (r & 1);
-      *reinterpret_cast<uint4*>(base + row * KROW + c * 16) = make_uint4(c == 5 ? 0x3F80u : 0u, 0, 0, 0);
+    if (r < 64 * C::KPADS) {
+      const int row = r / C::KPADS, c = C::NCH + (r - row * C::KPADS);
+      *reinterpret_cast<uint4*>(base + row * KROW + c * 16) = make_uint4(c == C::NCH ? 0x3F80u : 0u, 0, 0, 0);
     } else {
-      const int rr2 = r - 128, row = rr2 / 3, c = 5 + (rr2 - row * 3);
-      const int pos = c ^ (((row >> 1) & 1) << 2);
-      *reinterpret_cast<uint4*>(base + K_BYTES + row * VROW + pos * 16) = make_uint4(c == 5 ? 0x3F80u : 0u, 0, 0, 0);
+      const int rr2 = r - 64 * C::KPADS, row = rr2 / C::VPADS, c = C::NCH + (rr2 - row * C::VPADS);
+      const int pos = C::VSWZ ? c ^ (((row >> 1) & 1) << 2) : c;
+      *reinterpret_cast<uint4*>(base + K_BYTES + row * VROW + pos * 16) = make_uint4(c == C::NCH ? 0x3F80u : 0u, 0, 0, 0);
     }
   }
   f32x16 o[DB];
@@ -518,17 +563,25 @@ template <bool RUNMAX> __device__ __forceinline__ bool pass(const AttnParams& p,
   for (int d = 0; d < DB; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  float m_run = 0.f;
-  // fragment read addresses (per lane): K row l31 at 16 h; V rows 4 h + tq, swizzled 64-byte half, 8 tp + 32 gi
+  float m_run = EXACT ? -INFINITY : 0.f;
+  // fragment read addresses (per lane): K row l31 at 16 h; V rows 4 h + tq, (swizzled) 64-byte block, 8 tp + 32 gi
   const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) char*)smem);
   const unsigned kaddr0 = lds0 + (unsigned)(l31 * KROW + 16 * h);
+  const unsigned kaddr_last = C::KLASTFIX ? lds0 + (unsigned)(l31 * KROW) : kaddr0;   // last k step: both halves read chunk 2 (FS - 1)
   const int tq = (lane & 15) >> 2, tp = lane & 3, gi = (lane >> 4) & 1;
-  const int vrow0 = 4 * h + tq, sw = (vrow0 >> 1) & 1;
+  const int vrow0 = 4 * h + tq, sw = C::VSWZ ? (vrow0 >> 1) & 1 : 0;
   const unsigned vaddr0 = lds0 + (unsigned)(K_BYTES + vrow0 * VROW + 32 * gi + 8 * tp);
-  const unsigned vh0 = (unsigned)(64 * (0 ^ sw)), vh1 = (unsigned)(64 * (1 ^ sw));
 
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own pieces of tile 0 landed, own pads written
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own pieces of tile 0 landed, own pads written, Q here
   __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int s = 0; s < FS; ++s) {
+    Vec16<T> v;
+    v.u = qf[s];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v.e[e] = from_f32<T>(to_f32<T>(v.e[e]) * sl2);
+    qf[s] = v.u;
+  }
 
   for (int t = 0; t < nt; ++t) {
     const int t0 = t * 64;
@@ -541,15 +594,17 @@ template <bool RUNMAX> __device__ __forceinline__ bool pass(const AttnParams& p,
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
     {
-      const unsigned ka = kaddr0 + bo;
-      u32x4 a00 = lds_read128<0 * 32 * KROW + 0>(ka), a01 = lds_read128<0 * 32 * KROW + 32>(ka), a02 = lds_read128<0 * 32 * KROW + 64>(ka);
-      u32x4 a10 = lds_read128<1 * 32 * KROW + 0>(ka), a11 = lds_read128<1 * 32 * KROW + 32>(ka), a12 = lds_read128<1 * 32 * KROW + 64>(ka);
-      wait_lgkm<5>(a00); mma(a00, qf[0], s[0]);
-      wait_lgkm<4>(a01); mma(a01, qf[1], s[0]);
-      wait_lgkm<3>(a02); mma(a02, qf[2], s[0]);
-      wait_lgkm<2>(a10); mma(a10, qf[0], s[1]);
-      wait_lgkm<1>(a11); mma(a11, qf[1], s[1]);
-      wait_lgkm<0>(a12); mma(a12, qf[2], s[1]);
+      const unsigned ka = kaddr0 + bo, kl = kaddr_last + bo;
+      u32x4 a[2][FS];
+      sfor<0, 2 * FS>([&](auto mc) {
+        constexpr int m = decltype(mc)::value, kb = m / FS, st = m % FS;
+        a[kb][st] = (C::KLASTFIX && st == C::FS - 1) ? lds_read128<kb * 32 * KROW + 32 * st>(kl) : lds_read128<kb * 32 * KROW + 32 * st>(ka);
+      });
+      sfor<0, 2 * FS>([&](auto mc) {
+        constexpr int m = decltype(mc)::value, kb = m / FS, st = m % FS;
+        wait_lgkm<2 * FS - 1 - m>(a[kb][st]);
+        mma(a[kb][st], qf[st], s[kb]);
+      });
     }
     if (t0 + 64 > p.Nk) {  // partial last tile: mask keys >= Nk (wave-uniform branch)
 #pragma unroll
@@ -558,7 +613,7 @@ template <bool RUNMAX> __device__ __forceinline__ bool pass(const AttnParams& p,
         for (int r = 0; r < 16; ++r)
           if (t0 + 32 * kb + acc_row(r, h) >= p.Nk) s[kb][r] = -INFINITY;
     }
-    if (RUNMAX || t == 0) {
+    if (EXACT || RUNMAX || t == 0) {
       // tile maximum (see the kernel above for the wait states in front of the asm reads of MFMA results)
       float mxa, mxb, mxc, mxd;
       asm("s_nop 15\n\t"
@@ -576,7 +631,23 @@ template <bool RUNMAX> __device__ __forceinline__ bool pass(const AttnParams& p,
       mxa = max3f(mxa, s[0][7], s[0][15]); mxc = max3f(mxc, s[1][7], s[1][15]);
       float mx = max3f(mxa, mxb, mxc);
       mx = xhalf_max(fmaxf(mx, mxd));
-      const bool move = (t == 0) || mx > 24.0f;
+      if constexpr (EXACT) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+        m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {  // rescale only when some lane's maximum moved
+#pragma unroll
+          for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
+      }
+      const bool move = !EXACT && ((t == 0) || mx > 24.0f);
+      if constexpr (!EXACT)
       if (__builtin_amdgcn_ballot_w64(move) != 0) {
         const float m_new = move ? bf16_ceil(m_run + mx) : m_run;
         const float delta = m_new - m_run;  // exact: both are bf16 values
@@ -590,36 +661,40 @@ template <bool RUNMAX> __device__ __forceinline__ bool pass(const AttnParams& p,
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
         m_run = m_new;
-        if (h == MREF_HALF) {  // refresh the -m_ref slot of this lane's Q fragment
+        if (h == C::MREF_HALF) {  // refresh the -m_ref slot of this lane's Q fragment
           Vec16<T> v;
-          v.u = qf[MREF_STEP];
-          v.e[MREF_ELEM] = from_f32<T>(-m_new);
-          qf[MREF_STEP] = v.u;
+          v.u = qf[C::MREF_STEP];
+          v.e[C::MREF_ELEM] = from_f32<T>(-m_new);
+          qf[C::MREF_STEP] = v.u;
         }
       }
     }
+    if constexpr (!EXACT) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r]);
-    // ---- O^T += V^T P^T ----
-    {
-      const unsigned va0 = vaddr0 + bo + vh0, va1 = vaddr0 + bo + vh1;
-#define AF_PV_STEP(KB, S2)                                                                                           \
-      {                                                                                                              \
-        constexpr int RO = ((KB) * 32 + (S2) * 16) * VROW;                                                           \
-        u32x2 lo0 = lds_read_tr64<RO>(va0), hi0 = lds_read_tr64<RO + 8 * VROW>(va0);                                 \
-        u32x2 lo1 = lds_read_tr64<RO>(va1), hi1 = lds_read_tr64<RO + 8 * VROW>(va1);                                 \
-        Vec16<T> pb;                                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) pb.e[j] = from_f32<T>(s[KB][8 * (S2) + j]);                    \
-        wait_lgkm2<2>(lo0, hi0);                                                                                     \
-        mma(u32x4{lo0.x, lo0.y, hi0.x, hi0.y}, pb.u, o[0]);                                                          \
-        wait_lgkm2<0>(lo1, hi1);                                                                                     \
-        mma(u32x4{lo1.x, lo1.y, hi1.x, hi1.y}, pb.u, o[1]);                                                          \
-      }
-      AF_PV_STEP(0, 0) AF_PV_STEP(0, 1) AF_PV_STEP(1, 0) AF_PV_STEP(1, 1)
-#undef AF_PV_STEP
+        for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r]);
     }
+    // ---- O^T += V^T P^T : four k steps of 16 keys, DB blocks of 32 rows each ----
+    sfor<0, 4>([&](auto kc) {
+      constexpr int ks = decltype(kc)::value, KB = ks >> 1, S2 = ks & 1;
+      constexpr int RO = (KB * 32 + S2 * 16) * VROW;
+      u32x2 lo[DB], hi[DB];
+      sfor<0, DB>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        const unsigned va = vaddr0 + bo + (unsigned)(64 * (d ^ sw));   // (sw = 0 unless the rows are 128 bytes: then DB = 2)
+        lo[d] = lds_read_tr64<RO>(va);
+        hi[d] = lds_read_tr64<RO + 8 * VROW>(va);
+      });
+      Vec16<T> pb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb.e[j] = from_f32<T>(s[KB][8 * S2 + j]);
+      sfor<0, DB>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        wait_lgkm2<2 * (DB - 1 - d)>(lo[d], hi[d]);
+        mma(u32x4{lo[d].x, lo[d].y, hi[d].x, hi[d].y}, pb.u, o[d]);
+      });
+    });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of tile t+1 landed
     __builtin_amdgcn_s_barrier();                      // everyone's pieces landed; everyone is done reading tile t
   }
@@ -629,7 +704,7 @@ template <bool RUNMAX> __device__ __forceinline__ bool pass(const AttnParams& p,
   const float inv = 1.0f / l_tot;
   bool bad = !(l_tot > 0.f && l_tot < INFINITY);
   if (p.lse && q_ok && h == 0)
-    p.lse[((long)blockIdx.z * p.H + blockIdx.y) * p.Nq + q] = m_run + __builtin_amdgcn_logf(l_tot);
+    p.lse[((long)b * p.H + head) * p.Nq + q] = m_run + __builtin_amdgcn_logf(l_tot);
 #pragma unroll
   for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -649,13 +724,28 @@ template <bool RUNMAX> __device__ __forceinline__ bool pass(const AttnParams& p,
   return bad && q_ok;
 }
 
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_ring40_kernel(const AttnParams p) {
+template <int DH, int W = 8> __device__ __forceinline__ void ring_body(const AttnParams& p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  const bool bad = pass<false>(p, smem);
-  // (every DMA has been waited for and the last tile's barrier passed: LDS is free again)
-  if (__syncthreads_or(bad ? 1 : 0)) pass<true>(p, smem);
+  if constexpr (DH == 80) {
+    pass<DH, 2, W>(p, smem);       // exact running maximum: nothing can overflow, no repeat
+  } else {
+    const bool bad = pass<DH, 0, W>(p, smem);
+    // (every DMA has been waited for and the last tile's barrier passed: LDS is free again)
+    if (__syncthreads_or(bad ? 1 : 0)) pass<DH, 1, W>(p, smem);
+  }
 }
-}  // namespace ring40
+// dh 40: 128 VGPRs -> two workgroups per CU (four waves per SIMD)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_ring40_kernel(const AttnParams p) { ring_body<40>(p); }
+// dh 80: four waves = 128 queries per workgroup, three workgroups per CU (<= 170 VGPRs): three waves per SIMD that do not share
+// a barrier, and the plain online softmax (MODE 2: bit-identical to attn_kernel<bf16, 80>, so the bf16 forward does not move).
+// Measured, N = S = 1024, B = 16, with the first-tile reference (MODE 0; 3 % more rms error at the op level than the exact
+// maximum, whose largest P of a row is exactly 1.0): eight waves / two buffers / one workgroup per CU 63.2 us; eight waves with
+// the S^T MFMAs of tile t + 1 issued between the exponentials of tile t and a four-deep ring behind counted vmcnt waits 64.5-66.2 us
+// (in-kernel stamps: 17 % of a workgroup's cycles at the tile barrier -- the two waves of a SIMD reach their MFMA phases
+// together -- and 18-25 % in the prologue burst); four waves x three workgroups 60.0 us; the four-wave register-staged kernel
+// 79.8 us.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_ring80_kernel(const AttnParams p) { ring_body<80, 4>(p); }
+}  // namespace ring
 
 // ---------------------------------------------------------------------------------------------------------------
 // Cross-attention over a SHORT key list (the 77 context tokens; S <= 96), bf16, dh = 40 / 80 (the 64x64 and 32x32 levels).
@@ -854,10 +944,20 @@ template <typename T, int DH> static int launch_attn(const AttnParams& p, int B,
   if (int rc = af_ensure_dynamic_lds(attr_done, reinterpret_cast<const void*>(&attn_kernel<T, DH>), C::LDS_BYTES)) return rc;
   if (int rc = af_ensure_dynamic_lds(attr_done_w4, reinterpret_cast<const void*>(&attn_kernel_w4<T, DH>), C::LDS_BYTES)) return rc;
   if constexpr (C::BF && DH == 40) {
-    if (g_af_knobs.attn_ring && !p.causal) {   // eight-wave LDS-DMA ring kernel (the 64x64 level)
+    if ((g_af_knobs.attn_ring & 1) && !p.causal) {   // eight-wave LDS-DMA ring kernel (the 64x64 level)
       static unsigned long long attr_done_ring = 0;
-      if (int rc = af_ensure_dynamic_lds(attr_done_ring, reinterpret_cast<const void*>(&ring40::attn_ring40_kernel), ring40::LDS_BYTES)) return rc;
-      hipLaunchKernelGGL(ring40::attn_ring40_kernel, dim3((p.Nq + 255) / 256, p.H, B), dim3(ring40::NT), ring40::LDS_BYTES, stream, p);
+      if (int rc = af_ensure_dynamic_lds(attr_done_ring, reinterpret_cast<const void*>(&ring::attn_ring40_kernel), ring::Cfg<40>::LDS_BYTES)) return rc;
+      hipLaunchKernelGGL(ring::attn_ring40_kernel, dim3((p.Nq + 255) / 256, p.H, B), dim3(512), ring::Cfg<40>::LDS_BYTES, stream, p);
+      HIP_CHECK_RET(hipGetLastError());
+      return 0;
+    }
+  }
+  if constexpr (C::BF && DH == 80) {
+    if ((g_af_knobs.attn_ring & 2) && !p.causal && (p.Nk >= 256 || (g_af_knobs.attn_ring & 4))) {   // 80-wide heads (the 32x32 level; bit 2: tests force it for short key lists)
+      static unsigned long long attr_done_ring = 0;
+      constexpr int lds80 = ring::Cfg<80, 4>::LDS_BYTES;
+      if (int rc = af_ensure_dynamic_lds(attr_done_ring, reinterpret_cast<const void*>(&ring::attn_ring80_kernel), lds80)) return rc;
+      hipLaunchKernelGGL(ring::attn_ring80_kernel, dim3((p.Nq + 127) / 128, p.H, B), dim3(256), lds80, stream, p);
       HIP_CHECK_RET(hipGetLastError());
       return 0;
     }

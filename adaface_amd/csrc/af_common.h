@@ -86,7 +86,7 @@ struct AfKnobs {
   int gemm_groupm;          // AF_GEMM_GROUPM          >= 1: force the grouped tile order
   int gemm_dma;             // AF_GEMM_DMA             0 / 1: force register / LDS-DMA staging in the four-wave kernel
   int pp_direct;            // AF_PP_DIRECT            0 / 1: force the LDS / direct epilogue of the ping-pong kernel
-  int attn_ring;            // AF_ATTN_RING            0 = dh-40 bf16 attention on the four-wave kernel instead of the ring kernel
+  int attn_ring;            // AF_ATTN_RING            bit 0: dh-40, bit 1: dh-80 (>= 256 keys; bit 2: any key count) bf16 attention on the eight-wave ring kernel
   int gn_small;             // AF_GN_SMALL             0 = no single-launch GroupNorm for small maps
   int conv_tap_inner;       // AF_CONV_TAP_INNER       0 = ping-pong convs walk K tap-outermost (the round-1 order)
   int ln_fuse;              // AF_LN_FUSE              0 = stand-alone LayerNorm kernels in front of the transformer GEMMs

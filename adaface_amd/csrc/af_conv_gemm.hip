@@ -1372,6 +1372,21 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(const ConvGemmParams 
 //   Output rows, accumulators and the epilogue are those of conv_gemm_pp_kernel (the tile is 256 consecutive pixels in
 //   (b, y, x) raster order), K is walked (channel chunk, tap) and a K slice (split-K) is a whole number of chunks.
 // ---------------------------------------------------------------------------
+#ifdef AF_LAB_ABLATE
+// lab builds only: per-workgroup s_memrealtime stamps (100 MHz) of the halo kernel -- entry, loop start, loop end, stores
+// landed -- and the XCC / CU the workgroup ran on (scripts/lab/halo_stamps.py)
+__device__ unsigned long long g_lab_stamps[2048 * 5];
+extern "C" int af_lab_stamps(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lab_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+__device__ __forceinline__ unsigned long long lab_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#endif
 struct Halo8Cfg {
   static constexpr int BN = 160;
   static constexpr int HPIX = 400, HBUF = HPIX * 128, WBYTES = BN * 128;
@@ -1402,8 +1417,20 @@ __global__ __launch_bounds__(512) void conv3x3_halo8_kernel(const ConvGemmParams
   const int KT_all = p.K / 64;
   const int kt_per = (KT_all + p.splitk - 1) / p.splitk;
   const int kt_begin = zk * kt_per;
+#ifdef AF_LAB_ABLATE
+  // timing ablations (wrong results; scripts/lab/ablate_conv.sh halo): bits 4.. of the conv_fast_taps knob: 1 no LDS-DMA in
+  // the loop, 2 no fragment reads, 4 no MFMAs, 8 no epilogue, 16 one K step only, 32 no prologue staging
+  const int lab = p.fast_taps >> 4;
+  const int KT = (lab & 16) ? 1 : min(KT_all, kt_begin + kt_per) - kt_begin;
+#else
+  constexpr int lab = 0;
   const int KT = min(KT_all, kt_begin + kt_per) - kt_begin;
+#endif
   const int chunk0 = kt_begin / 9;
+#ifdef AF_LAB_ABLATE
+  unsigned long long st0 = 0, st1 = 0, st2 = 0;
+  if (lab & 64) st0 = lab_now();
+#endif
 
   // ---- geometry: the tile is R rows of image b starting at row y0 ----
   const int Wo = p.Wo, HW = Wo + 2, wsh = p.wo_shift;
@@ -1463,6 +1490,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo8_kernel(const ConvGemmParams
 #pragma unroll
   for (int j = 0; j < MI; ++j) xa8[j][0] = xa8[j][1] = xb8[j][0] = xb8[j][1] = pp_u32x4{0u, 0u, 0u, 0u};
   auto mfma2 = [&](f32x4& c, const pp_u32x4 (&wv)[2], const pp_u32x4 (&xv)[2]) {
+    if (lab & 4) return;
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[0]), __builtin_bit_cast(bf16x8, xv[0]), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[1]), __builtin_bit_cast(bf16x8, xv[1]), c, 0, 0, 0);
     asm volatile("" : "+v"(c));
@@ -1474,14 +1502,19 @@ __global__ __launch_bounds__(512) void conv3x3_halo8_kernel(const ConvGemmParams
 
   // ---- staging (everything by value: see KWalk in conv_gemm_pp_kernel) ----
   struct Step { int tap, chunk; };             // the step being STAGED (weights) / the chunk whose halo is being staged
+  bool in_loop = false;
   auto stage_w = [&](auto qc, int wslot, Step st, int live) {
     constexpr int q = decltype(qc)::value;
+    if ((lab & 1) && in_loop) return;
+    if ((lab & 32) && !in_loop) return;
     const unsigned k0b = (unsigned)(st.tap * p.Cin + st.chunk * 64) * 2u;
     const unsigned a = live ? w_off[q] : 0xFFFFFFFFu;
     lds_dma16(rs_w, smem + H::W_BASE + wslot * H::WBYTES + (wid + 8 * q) * 1024, a, k0b);
   };
   auto stage_h = [&](auto qc, int hbuf, int chunk, int live) {
     constexpr int q = decltype(qc)::value;
+    if ((lab & 1) && in_loop) return;
+    if ((lab & 32) && !in_loop) return;
     const unsigned a = live ? h_off[q] : 0xFFFFFFFFu;
     lds_dma16(rs_x, smem + hbuf * H::HBUF + (wid + 8 * q) * 1024, a, (unsigned)chunk * 128u);
   };
@@ -1514,6 +1547,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo8_kernel(const ConvGemmParams
     const unsigned wb1 = lds0 + (unsigned)(H::W_BASE + ws * H::WBYTES) + w_base + fch1;
     auto rd_block = [&](auto bc) {
       constexpr int bi = decltype(bc)::value;
+      if (lab & 2) return;
       if constexpr (bi == 0) {
         w8[0][0] = pp_lds_read128<0>(wb0);
         w8[0][1] = pp_lds_read128<0>(wb1);
@@ -1599,6 +1633,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo8_kernel(const ConvGemmParams
     const int t3 = ws; ws = ws1; ws1 = ws2; ws2 = t3;
   };
   int t = 0;
+  in_loop = true;
+#ifdef AF_LAB_ABLATE
+  if (lab & 64) st1 = lab_now();
+#endif
   for (; t + 1 < KT; t += 2) {
     one(xa8, xb8);
     one(xb8, xa8);
@@ -1613,6 +1651,18 @@ __global__ __launch_bounds__(512) void conv3x3_halo8_kernel(const ConvGemmParams
     for (int j = 0; j < MI; ++j) mfma2(acc[NI - 1][j], w8[NI - 1], xb8[j]);
   }
   __builtin_amdgcn_s_barrier();
+#ifdef AF_LAB_ABLATE
+  if (lab & 64) st2 = lab_now();
+#endif
+  if (lab & 8) {   // keep the accumulators alive behind a condition that never holds
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MI; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum == 12345.678f) reinterpret_cast<float*>(p.out)[tid] = sum;
+    return;
+  }
 
   const int cl = 4 * (lane >> 4);
   float4 bias_r[NI];
@@ -1624,6 +1674,20 @@ __global__ __launch_bounds__(512) void conv3x3_halo8_kernel(const ConvGemmParams
   float4 ln_cs[1];
   float ln_mu[1], ln_rs[1];
   pp_epilogue<160, 0>(p, acc, bias_r, ln_cs, ln_mu, ln_rs, smem, tid, lane, g, wq, m0, n0, tn, zk);
+#ifdef AF_LAB_ABLATE
+  if (lab & 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned long long st3 = lab_now();
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    if (tid == 0 && blockIdx.x < 2048 && blockIdx.z == 0) {
+      unsigned long long* o = g_lab_stamps + (long)blockIdx.x * 5;
+      o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = ((unsigned long long)xcc << 32) | hwid;
+    }
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -50,7 +50,7 @@ AfKnobs g_af_knobs = {
     knob_env("AF_SPLITK_TARGET", 320), knob_env("AF_CONV_HALO", 1),       knob_env("AF_GEMM_PP", 1),
     knob_env("AF_GEMM_PP_MINFILL", 50), knob_env("AF_GEMM_TILE", -1),
     knob_env("AF_GEMM_SPLITK", -1),    knob_env("AF_GEMM_GROUPM", -1),    knob_env("AF_GEMM_DMA", -1),
-    knob_env("AF_PP_DIRECT", -1),      knob_env("AF_ATTN_RING", 1),
+    knob_env("AF_PP_DIRECT", -1),      knob_env("AF_ATTN_RING", 3),
     knob_env("AF_GN_SMALL", 1),        knob_env("AF_CONV_TAP_INNER", 1),
     knob_env("AF_LN_FUSE", 1),         knob_env("AF_GEGLU_ROWPANEL", 4), knob_env("AF_CONV_HALO8", 3), knob_env("AF_CONV_FAST_TAPS", 1),
     knob_env("AF_PP_STAGGER", 1),      knob_env("AF_GN_PRODUCER", 1),     knob_env("AF_CONV_UP_PHASE4", 1),

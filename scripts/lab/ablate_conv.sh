@@ -15,6 +15,13 @@ if [ "$1" = build ]; then
   hipcc -shared -fPIC --offload-arch=gfx950 -o scripts/lab/ab/lib_lab.so /tmp/af_lab/*.o
   exit 0
 fi
+if [ "$1" = halo ]; then
+  for k in 1 17 33 65 129 257 385 897 113; do
+    echo "== halo kernel, conv_fast_taps=$k (+16 no LDS-DMA in the loop, +32 no reads, +64 no MFMAs, +128 no epilogue, +256 one K step, +512 no prologue staging)"
+    python scripts/bench_shapes.py --only conv8 --lib scripts/lab/ab/lib_lab.so --knob conv_fast_taps=$k 2>&1 | grep "320->320@64 B16 bf16\|640->640@32 B16 bf16\|640->320@64 B16 bf16"
+  done
+  exit 0
+fi
 if [ "$1" = geglu ]; then
   for k in 1 17 33 65 129 97 225; do
     echo "== geglu row-panel, conv_fast_taps=$k (+16 no LDS-DMA, +32 no reads, +64 no MFMAs, +128 no epilogue)"

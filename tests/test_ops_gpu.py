@@ -575,10 +575,11 @@ def test_to_uint8(gpu):
     assert (got == ref).all(), int((got != ref).sum())
 
 
+@pytest.mark.parametrize("dh", [40, 80])
 @pytest.mark.parametrize("ring", [1, 0])
 @pytest.mark.parametrize("spike", [6.0, 24.0])
-def test_attention_spiky_bf16_dh40(gpu, report, knobs, ring, spike):
-    """bf16 dh = 40 kernels (the 64x64-level attention).  Their softmax reference rides in a spare K slot of the QK^T
+def test_attention_spiky_bf16_dh40(gpu, report, knobs, ring, spike, dh):
+    """bf16 dh = 40 / 80 kernels (the 64x64- and 32x32-level attention).  Their softmax reference rides in a spare K slot of the QK^T
     MFMA.  The eight-wave ring kernel (ring = 1) takes it from the FIRST key tile only and repeats a query block with the
     running-reference loop when a later score overflows exp2 (more than 2^127 above it); the four-wave kernel (ring = 0)
     moves the reference when a score rises more than 2^24 above it.  A key in a LATE tile aligned with one query and
@@ -586,9 +587,9 @@ def test_attention_spiky_bf16_dh40(gpu, report, knobs, ring, spike):
     kernel, large-but-finite P in the ring kernel), spike 24 -> +220 (overflow -> repeat in the ring kernel).  Queries
     that do not see the spike take the common path in the same launch."""
     from adaface_amd import ops
-    knobs("attn_ring", ring)
+    knobs("attn_ring", 3 * ring)
     g = torch.Generator().manual_seed(6)
-    B, N, heads, dh = 1, 512, 8, 40
+    B, N, heads = 1, 512, 8
     q = _q(torch.randn(B, N, heads * dh, generator=g), "bf16")
     k = _q(torch.randn(B, N, heads * dh, generator=g), "bf16")
     v = _q(torch.randn(B, N, heads * dh, generator=g), "bf16")
@@ -601,7 +602,7 @@ def test_attention_spiky_bf16_dh40(gpu, report, knobs, ring, spike):
     got = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), heads, dtype="bf16")
     assert torch.isfinite(got).all()
     if spike <= 8:
-        _cmp(report, f"attention spiky dh40 ring{ring} spike{spike:g}", got, ref, "bf16")
+        _cmp(report, f"attention spiky dh{dh} ring{ring} spike{spike:g}", got, ref, "bf16")
     else:
         # The kernels round the pre-scaled Q (q * scale * log2 e) to bf16: component d of a query moves by <= 2^-9 relative, so
         # the score against key j moves by <= delta_ij = 2^-9 * scale * log2(e) * sum_d |q_id| |k_jd| units of the log2
@@ -622,9 +623,9 @@ def test_attention_spiky_bf16_dh40(gpu, report, knobs, ring, spike):
         err = (got.cpu() - ref).abs().view(B, N, heads, dh).amax(-1).transpose(1, 2)      # [B, H, N]
         bar = TOL["bf16"] * scale + E
         worst = (err / bar).max().item()
-        report(f"attention spiky dh40 ring{ring} spike{spike:g}: worst row error / (bf16 bar + the row's Q-rounding bound)[bf16]",
+        report(f"attention spiky dh{dh} ring{ring} spike{spike:g}: worst row error / (bf16 bar + the row's Q-rounding bound)[bf16]",
                worst, 1.0, 1.0)
-        report(f"attention spiky dh40 ring{ring} spike{spike:g}: rows whose bound is below the bf16 bar[bf16]",
+        report(f"attention spiky dh{dh} ring{ring} spike{spike:g}: rows whose bound is below the bf16 bar[bf16]",
                (err * (E < TOL["bf16"] * scale)).max().item(), scale, 2.0 * TOL["bf16"] * scale)
         assert (E > TOL["bf16"] * scale).float().mean().item() < 0.25      # the loosened rows are a minority
         assert worst <= 1.0, worst
@@ -633,18 +634,21 @@ def test_attention_spiky_bf16_dh40(gpu, report, knobs, ring, spike):
     assert (got[0, 300].cpu() - ref[0, 300]).abs().max() <= 1.5e-2 * ref.abs().max()
 
 
+@pytest.mark.parametrize("dh", [40, 80])
 @pytest.mark.parametrize("B,Nq,Nk,heads", [(2, 300, 333, 8), (1, 256, 77, 8), (3, 70, 64, 2), (1, 1024, 1, 8), (2, 513, 129, 4)])
-def test_attention_dh40_ring_shapes(gpu, report, B, Nq, Nk, heads):
-    """Ragged shapes through the ring kernel: partial query blocks, partial / single key tiles, one key."""
+def test_attention_dh40_ring_shapes(gpu, report, knobs, B, Nq, Nk, heads, dh):
+    """Ragged shapes through the ring kernel (dh 40, and dh 80 forced onto it for short key lists too): partial query
+    blocks, partial / single key tiles, one key."""
     from adaface_amd import ops
+    knobs("attn_ring", 7)
     g = torch.Generator().manual_seed(Nq + Nk)
-    C = heads * 40
+    C = heads * dh
     q = _q(torch.randn(B, Nq, C, generator=g), "bf16")
     k = _q(torch.randn(B, Nk, C, generator=g), "bf16")
     v = _q(torch.randn(B, Nk, C, generator=g), "bf16")
     ref = _ref_attention(q, k, v, heads)
     got = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), heads, dtype="bf16")
-    _cmp(report, f"attention ring N{Nq} S{Nk} h{heads} d40", got, ref, "bf16")
+    _cmp(report, f"attention ring N{Nq} S{Nk} h{heads} d{dh}", got, ref, "bf16")
 
 
 @pytest.mark.parametrize("B,Nq,Nk,heads,dh", [
@@ -731,22 +735,42 @@ def test_cross_attention_layer_in_one_kernel(gpu, report, B, N, S):
         assert torch.allclose(parts[part][:, 1].double(), s2, rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("Nk", [77, 129])
-def test_attention_dh40_ring_nan_guard(gpu, report, Nk):
+@pytest.mark.parametrize("B,Nq,Nk,heads", [(16, 1024, 1024, 8), (2, 300, 333, 8), (1, 513, 129, 4), (3, 70, 64, 2)])
+def test_attention_dh80_ring_bit_identical(gpu, knobs, B, Nq, Nk, heads):
+    """The dh-80 ring kernel (four-wave workgroups sharing LDS-DMA-staged K / V tiles, round 4) runs the same online softmax,
+    MFMA for MFMA, as the four-wave register-staged kernel it replaces at the 32x32 level: outputs are equal BIT FOR BIT, at
+    the benchmark shape and on ragged ones (so the bf16 forward, and every bar measured on it, does not move)."""
+    from adaface_amd import ops
+    g = torch.Generator().manual_seed(B + Nq + Nk)
+    C = heads * 80
+    q = _q(torch.randn(B, Nq, C, generator=g) * 1.3, "bf16").to(gpu)
+    k = _q(torch.randn(B, Nk, C, generator=g) * 1.3, "bf16").to(gpu)
+    v = _q(torch.randn(B, Nk, C, generator=g), "bf16").to(gpu)
+    knobs("attn_ring", 7)
+    new = ops.attention(q, k, v, heads, dtype="bf16")
+    knobs("attn_ring", 1)
+    old = ops.attention(q, k, v, heads, dtype="bf16")
+    assert torch.isfinite(new).all()
+    assert torch.equal(new, old), (new.float() - old.float()).abs().max().item()
+
+
+@pytest.mark.parametrize("dh,Nk", [(40, 77), (40, 129), (80, 129), (80, 300)])
+def test_attention_dh40_ring_nan_guard(gpu, report, knobs, dh, Nk):
     """the ring kernel zero-fills rows >= Nk of the last key tile through the buffer range check.  K and V are
     placed in front of 128 rows of NaNs (af_op_attention flag bit 1): a kernel that really read those rows would turn
     0 * NaN into NaN in O (finite garbage there is invisible: P is 0).  One run, finite and matching."""
     from adaface_amd import ops
+    knobs("attn_ring", 7)       # (dh 80: the ring kernel for fewer than 256 keys too)
     g = torch.Generator().manual_seed(1000 + Nk)
     B, Nq, heads = 2, 512, 8
-    C = heads * 40
+    C = heads * dh
     q = _q(torch.randn(B, Nq, C, generator=g), "bf16")
     k = _q(torch.randn(B, Nk, C, generator=g), "bf16")
     v = _q(torch.randn(B, Nk, C, generator=g), "bf16")
     ref = _ref_attention(q, k, v, heads)
     got = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), heads, dtype="bf16", nan_guard=True)
     assert torch.isfinite(got).all(), "ring kernel read K/V rows past Nk"
-    _cmp(report, f"attention ring nan-guard S{Nk}", got, ref, "bf16")
+    _cmp(report, f"attention ring nan-guard d{dh} S{Nk}", got, ref, "bf16")
 
 
 # ---------------------------------------------------------------------------------------------------------------
