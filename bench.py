@@ -330,7 +330,7 @@ def main():
         if launches[d]:
             traffic, tsrc = traffic_record() if d == DOMINANT else (None, None)
             ach = flops[d] / (ms[d] * 1e-3)
-            kname = {DOMINANT: DOMINANT_KERNEL + " (3x3 / stride-1 convolutions of the UNet at 64x64 / 32x32 / 16x16: eight-wave "
+            kname = {DOMINANT: DOMINANT_KERNEL + " (3x3 / stride-1 convolutions of the UNet at 64x64 / 32x32: eight-wave "
                                "256x160x64 implicit GEMM, input halo resident in LDS, weight tiles by LDS-DMA, merged "
                                "staging/compute schedule)",
                      DOMINANT_FP8: DOMINANT_FP8_KERNEL + " (ResBlock 3x3 convolutions with OCP e4m3 operands on "
