@@ -108,7 +108,17 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   const int tid = threadIdx.x, b = blockIdx.x;
   const int g = tid & 31, sl = tid >> 5;
   double a = 0.0, q = 0.0;
-  for (int c = sl; c < nchunk; c += 8) {
+  // (eight loads in flight, added in the order of the plain loop: the VAE decoder's 512 x 512 maps bring > 1000 chunks per
+  // sample and one load latency per chunk made this 27 us per launch)
+  int c = sl;
+  for (; c + 56 < nchunk; c += 64) {
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(partial + (((long)b * nchunk + c + 8 * u) * GN_GROUPS + g) * 2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a += (double)v[u].x; q += (double)v[u].y; }
+  }
+  for (; c < nchunk; c += 8) {
     const float* src = partial + (((long)b * nchunk + c) * GN_GROUPS + g) * 2;
     a += (double)src[0];
     q += (double)src[1];
