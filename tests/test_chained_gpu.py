@@ -11,6 +11,11 @@ tolerances, relative to max|final latent| of the f32 mode:
     final latent after the chain:                                  bf16 <= 3e-2, fp8 <= 1e-1
     and, derived from the measured per-forward error e1 of the same run:  final <= CHAIN_GAIN * e1  (the chain may not
     amplify the per-forward error by more than the stated gain; measured gains are written to parity_report.txt)
+
+Round 4 adds the RMS of the final deviation (relative to the rms of the f32 latent) under the same numbers.  The max-abs
+statistic is a draw of the rounding noise: scaling x_T by 1 + k * 1e-6 (k = 0..5) moves it over 2.68e-2 .. 3.05e-2 for ONE
+build (scripts/lab/chained_sensitivity.py; a kernel that only changes an fp32 summation order does the same), while the rms
+stays within 2.62e-2 .. 2.64e-2 -- a change of the rms is a change of the arithmetic, a change of the max-abs need not be.
 """
 import json
 import os
@@ -28,6 +33,7 @@ pytestmark = pytest.mark.gpu
 
 FWD_BAR = {"bf16": 3e-2, "fp8": 8e-2}
 FINAL_BAR = {"bf16": 3e-2, "fp8": 1e-1}
+FINAL_RMS_BAR = {"bf16": 3e-2, "fp8": 1e-1}     # rms(final - f32 final) / rms(f32 final): the stable statistic (see above)
 CHAIN_GAIN = 2.5
 
 
@@ -72,6 +78,11 @@ def test_config1_shape_chained_error_bf16_fp8_vs_f32(gpu, report, bench_model, w
         report(f"{workload} shape Bf=16: first-forward eps {mode} vs f32 mode", e1, e_scale, FWD_BAR[mode])
         report(f"{workload} shape Bf=16: final latent after S=10 DDIM steps {mode} vs f32 mode", ef, l_scale, FINAL_BAR[mode])
         report(f"{workload} shape Bf=16: chain gain (final / first-forward) {mode}", ef / e1, 1.0, CHAIN_GAIN)
+        d = (out[mode][1] - out["f32"][1]).double()
+        l_rms = out["f32"][1].double().pow(2).mean().sqrt().item()
+        erms = d.pow(2).mean().sqrt().item() / l_rms
+        report(f"{workload} shape Bf=16: final latent after S=10 DDIM steps {mode} vs f32 mode, rms / rms", erms, l_rms, FINAL_RMS_BAR[mode])
+        assert erms <= FINAL_RMS_BAR[mode], (mode, erms)
         assert e1 <= FWD_BAR[mode], (mode, e1)
         assert ef <= FINAL_BAR[mode], (mode, ef)
         assert ef <= CHAIN_GAIN * e1, (mode, ef, e1)
