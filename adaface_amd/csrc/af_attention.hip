@@ -167,8 +167,10 @@ template <typename T, int DH> __device__ __forceinline__ void attn_body(const At
     Vec16<T> v;
     v.u = make_uint4(0, 0, 0, 0);
     if (q_ok && d0 < DH) v.u = *reinterpret_cast<const uint4*>(Q + (long)q * p.ldq + d0);
+    if constexpr (C::MREF) {   // (the m_ref slot rides in the contraction: its scores must already be in the log2 domain)
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) v.e[e] = from_f32<T>(to_f32<T>(v.e[e]) * sl2);
+      for (int e = 0; e < EPC; ++e) v.e[e] = from_f32<T>(to_f32<T>(v.e[e]) * sl2);
+    }
     qf[s] = v.u;
   }
 
@@ -286,14 +288,16 @@ template <typename T, int DH> __device__ __forceinline__ void attn_body(const At
         }
       if constexpr (!C::ONES) l_run += psum;
     } else {
+      // Q is NOT pre-scaled here (no second bf16 rounding of q): scale * log2(e) enters in the fp32 fma in front of the exponential
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
+      const float msl = m_new * sl2;
       float psum = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+          const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sl2, -msl));
           s[kb][r] = pv;
           if constexpr (!C::ONES) psum += pv;
         }
@@ -362,7 +366,7 @@ template <typename T, int DH> __device__ __forceinline__ void attn_body(const At
   }
   const float inv = 1.0f / l_tot;
   if (p.lse && q_ok && h == 0)
-    p.lse[((long)blockIdx.z * p.H + blockIdx.y) * p.Nq + q] = m_run + __builtin_amdgcn_logf(l_tot);
+    p.lse[((long)blockIdx.z * p.H + blockIdx.y) * p.Nq + q] = (C::MREF ? m_run : m_run * sl2) + __builtin_amdgcn_logf(l_tot);
   if (q_ok) {
 #pragma unroll
     for (int d = 0; d < DB; ++d)
@@ -578,8 +582,10 @@ template <int DH, int MODE, int W = 8> __device__ __forceinline__ bool pass(cons
   for (int s = 0; s < FS; ++s) {
     Vec16<T> v;
     v.u = qf[s];
+    if constexpr (!EXACT) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v.e[e] = from_f32<T>(to_f32<T>(v.e[e]) * sl2);
+      for (int e = 0; e < 8; ++e) v.e[e] = from_f32<T>(to_f32<T>(v.e[e]) * sl2);
+    }
     qf[s] = v.u;
   }
 
@@ -633,11 +639,12 @@ template <int DH, int MODE, int W = 8> __device__ __forceinline__ bool pass(cons
       mx = xhalf_max(fmaxf(mx, mxd));
       if constexpr (EXACT) {
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
+        const float msl = m_new * sl2;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+          for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sl2, -msl));
         m_run = m_new;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {  // rescale only when some lane's maximum moved
 #pragma unroll
@@ -704,7 +711,7 @@ template <int DH, int MODE, int W = 8> __device__ __forceinline__ bool pass(cons
   const float inv = 1.0f / l_tot;
   bool bad = !(l_tot > 0.f && l_tot < INFINITY);
   if (p.lse && q_ok && h == 0)
-    p.lse[((long)b * p.H + head) * p.Nq + q] = m_run + __builtin_amdgcn_logf(l_tot);
+    p.lse[((long)b * p.H + head) * p.Nq + q] = (EXACT ? m_run * sl2 : m_run) + __builtin_amdgcn_logf(l_tot);
 #pragma unroll
   for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -820,10 +827,8 @@ __global__ __launch_bounds__(256) void xattn_short_kernel(const AttnParams p, co
       Vec16<T> v;
       v.u = make_uint4(0, 0, 0, 0);
       if (key < p.Nk && d0 < DH) v.u = *reinterpret_cast<const uint4*>(K + (long)key * p.ldk + d0);
-      // scale * log2(e) rides on the resident K fragments (rounded to bf16 once per wave, as the flash kernels round their
-      // pre-scaled Q): the per-block Q fragments go into the MFMA as loaded, and softmax is exp2(s - m)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v.e[e] = from_f32<T>(to_f32<T>(v.e[e]) * sl2);
+      // K and Q go into the MFMA as loaded (round 4: scale * log2(e) used to ride on these fragments, a second bf16 rounding
+      // of K); the factor enters in the fp32 fma in front of the exponential: softmax is exp2(s * sl2 - m * sl2)
       kf[kb][s] = v.u;
     }
   uint4 vf[C::DB][C::VSTEPS];
@@ -871,6 +876,7 @@ __global__ __launch_bounds__(256) void xattn_short_kernel(const AttnParams p, co
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
     }
     mx = xhalf_max(mx);
+    const float msl = mx * sl2;
     uint4 pb[NKB][2];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
@@ -878,7 +884,7 @@ __global__ __launch_bounds__(256) void xattn_short_kernel(const AttnParams p, co
       for (int s2 = 0; s2 < 2; ++s2) {
         Vec16<T> v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v.e[j] = from_f32<T>(__builtin_amdgcn_exp2f(sc[kb][8 * s2 + j] - mx));
+        for (int j = 0; j < 8; ++j) v.e[j] = from_f32<T>(__builtin_amdgcn_exp2f(fmaf(sc[kb][8 * s2 + j], sl2, -msl)));
         pb[kb][s2] = v.u;
       }
     // ---- O^T = V^T P^T (row DH = the softmax denominator) ----

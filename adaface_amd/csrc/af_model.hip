@@ -236,7 +236,7 @@ struct CtxKV {  // cached cross-attention K/V for one transformer block
   int C = 0;
   void* vt = nullptr;   // V packed as the resident fragments of the short-key cross-attention kernel (bf16, dh 40 / 80), or null
   size_t vt_bytes = 0;
-  void* xf_pack = nullptr;   // K (pre-scaled) and V packed per head pair for xattn_fused_kernel (bf16, C = 320, <= 80 keys), or null
+  void* xf_pack = nullptr;   // K and V packed per head pair for xattn_fused_kernel (bf16, C = 320, <= 80 keys), or null
   size_t xf_bytes = 0;
 };
 
@@ -2078,7 +2078,7 @@ int af_set_context(af_handle* h, const float* ctx_dev, int Bf, int n_tokens, int
     p.M = Bf * n_tokens; p.N = 2 * C; p.K = D;
     p.out = h->ctx_kv[i].kv; p.ldo = 2 * C; p.alpha = 1.0f;
     AF_TRY(DISPATCH(dt, af_launch_conv_gemm<bf16>(p, 1, s), af_launch_conv_gemm<float>(p, 1, s)));
-    if (h->ctx_kv[i].xf_pack)   // K (x scale log2 e) and V of this layer as the operand fragments of xattn_fused_kernel
+    if (h->ctx_kv[i].xf_pack)   // K and V of this layer as the operand fragments of xattn_fused_kernel
       AF_TRY(af_launch_xattn_fused_pack(h->ctx_kv[i].kv, 2 * C, (long)n_tokens * 2 * C, n_tokens, Bf, 1.0f / sqrtf((float)x.dh),
                                         h->ctx_kv[i].xf_pack, s));
     if (h->ctx_kv[i].vt)   // V of this layer as resident fragments (rows of the key list as they now stand)

@@ -17,7 +17,7 @@
 //                                     The accumulator of a 16x16x32 MFMA holds, per lane, 4 consecutive channels of one
 //                                     token -- two such blocks ARE a B-operand fragment (token on the lane, 8 K values), for
 //                                     any fixed assignment of channels to K slots: no LDS, no shuffles.
-//   phase 2  per head: S^T = K q^T    K pre-scaled by scale * log2(e) and PACKED per layer at af_set_context in exactly that
+//   phase 2  per head: S^T = K q^T    K PACKED per layer at af_set_context (as stored; scale * log2(e) enters in the fma in front of exp2) in exactly that
 //            softmax, O^T = V^T P^T   K-slot order (pack_kv_kernel); the packs of a head pair (38 KB) are staged by LDS-DMA
 //                                     into one of two buffers while the previous pair computes.  S^T accumulators -> P^T operand
 //                                     and O^T accumulators -> operand of phase 3 by the same trick; the softmax denominator is
@@ -102,7 +102,7 @@ __host__ __device__ inline int wo_pos_channel(int kc, int pos) {
   return r < 8 ? 80 * pair + 32 + r : 80 * pair + 40 + (r - 8);
 }
 
-__global__ __launch_bounds__(256) void pack_kv_kernel(const bf16* __restrict__ kv, int ldk, long bsk, int Nk, int B, float sl2,
+__global__ __launch_bounds__(256) void pack_kv_kernel(const bf16* __restrict__ kv, int ldk, long bsk, int Nk, int B,
                                                       bf16* __restrict__ pack) {
   const long total = (long)B * NPAIR * PACK_ELEMS_PER_PAIR;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void pack_kv_kernel(const bf16* __restrict__ k
     if (frag < K_FRAGS) {
       const int s = frag & 1, kb = (frag >> 1) % NKB, hh = (frag >> 1) / NKB;
       const int key = 16 * kb + l15, d = k_slot_channel(pair, hh, s, g, j);
-      if (key < Nk && d >= 0) val = (float)kv[(long)b * bsk + (long)key * ldk + (2 * pair + hh) * DH + d] * sl2;
+      if (key < Nk && d >= 0) val = (float)kv[(long)b * bsk + (long)key * ldk + (2 * pair + hh) * DH + d];   // (as stored: scale * log2 e enters in front of the exponential)
     } else if (frag < K_FRAGS + V_FRAGS) {
       const int f = frag - K_FRAGS;
       const int sp = f % NSP, blk = (f / NSP) % 3, hh = f / (3 * NSP);
@@ -208,6 +208,7 @@ struct Params {
   void* out; int ldo;
   float* ln_stats_out;                   // [4][M][2] partial sums of the stored rows (parts 0 / 2 = columns 0-159 / 160-319), or null
   int Nk;
+  float sl2;                             // dh^-1/2 * log2(e): multiplies the raw scores in the fma in front of exp2
   int lab;                               // -DAF_LAB_ABLATE builds only: timing ablations (wrong results), see scripts/lab/ablate_xattn.sh
 };
 
@@ -487,7 +488,8 @@ __global__ __launch_bounds__(512) void xattn_fused_kernel(const Params p) {
         }
         u32x4 pb[NSP];
         {
-          const f32x2 mx2 = f32x2{mx, mx};
+          const float msl = mx * p.sl2;
+          const f32x2 sl2v = f32x2{p.sl2, p.sl2}, nm2 = f32x2{-msl, -msl};
 #pragma unroll
           for (int sp = 0; sp < NSP; ++sp) {
             unsigned w[4];
@@ -495,7 +497,8 @@ __global__ __launch_bounds__(512) void xattn_fused_kernel(const Params p) {
             for (int hb = 0; hb < 2; ++hb) {
               const int kb = 2 * sp + hb;
               if (kb < NKB) {
-                const f32x2 d0 = f32x2{sc[j][kb][0], sc[j][kb][1]} - mx2, d1 = f32x2{sc[j][kb][2], sc[j][kb][3]} - mx2;   // v_pk_add_f32
+                const f32x2 d0 = __builtin_elementwise_fma(f32x2{sc[j][kb][0], sc[j][kb][1]}, sl2v, nm2);   // v_pk_fma_f32
+                const f32x2 d1 = __builtin_elementwise_fma(f32x2{sc[j][kb][2], sc[j][kb][3]}, sl2v, nm2);
                 w[2 * hb] = pack2(__builtin_amdgcn_exp2f(d0.x), __builtin_amdgcn_exp2f(d0.y));
                 w[2 * hb + 1] = pack2(__builtin_amdgcn_exp2f(d1.x), __builtin_amdgcn_exp2f(d1.y));
               } else {
@@ -718,8 +721,9 @@ int af_launch_xattn_fused_pack(const void* kv, int ldk, long bsk, int Nk, int B,
   const long total = (long)B * xf::NPAIR * xf::PACK_ELEMS_PER_PAIR;
   unsigned blocks = (unsigned)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
+  (void)scale;   // (round 4: K is packed as stored -- no second bf16 rounding; the kernel multiplies the scores by scale * log2 e in fp32)
   hipLaunchKernelGGL(xf::pack_kv_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const bf16*>(kv), ldk, bsk, Nk, B,
-                     scale * 1.44269504088896340736f, reinterpret_cast<bf16*>(pack));
+                     reinterpret_cast<bf16*>(pack));
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -748,6 +752,7 @@ int af_launch_xattn_fused(const AfXattnFusedParams& a, hipStream_t stream) {
   p.kvpack = a.kvpack; p.rows_per_sample = a.rows_per_sample;
   p.wo = a.wo; p.ldwo = a.ldwo; p.o_bias = a.o_bias;
   p.out = a.out; p.ldo = a.ldo; p.ln_stats_out = a.ln_stats_out; p.Nk = a.Nk;
+  p.sl2 = 1.0f / sqrtf((float)xf::DH) * 1.44269504088896340736f;   // (the expression of the unfused kernels: p.scale * log2 e)
   p.lab = g_af_knobs.xattn_fused >> 4;
   // algorithmic work of the three launches it replaces: two [M, 320] x [320, 320] projections + the attention
   const double flops = 2.0 * 2.0 * a.M * (double)xf::C * xf::C + 4.0 * a.M * (double)a.Nk * xf::C;
