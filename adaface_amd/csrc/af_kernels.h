@@ -27,7 +27,7 @@ struct AfXattnFusedParams {
 };
 bool af_xattn_fused_ok(int M, int rows_per_sample, int C, int H, int dh, int Nk);
 long af_xattn_fused_pack_elems(int B, int H, int dh, int Nk);         // bf16 elements of the K / V pack of one layer (0 = no such kernel)
-int af_launch_xattn_fused_pack(const void* kv, int ldk, long bsk, int Nk, int B, float scale, void* pack, hipStream_t stream);
+int af_launch_xattn_fused_pack(const void* kv, int ldk, long bsk, int Nk, int B, void* pack, hipStream_t stream);   // K as stored: the kernel applies dh^-1/2 * log2 e in fp32
 int af_launch_xattn_fused_permute_wo(const void* w, int ldw, int rows, void* wp, int ldp, hipStream_t stream);
 int af_launch_xattn_fused(const AfXattnFusedParams& a, hipStream_t stream);
 extern std::atomic<long> g_af_xattn_fused_launches;

@@ -2079,7 +2079,7 @@ int af_set_context(af_handle* h, const float* ctx_dev, int Bf, int n_tokens, int
     p.out = h->ctx_kv[i].kv; p.ldo = 2 * C; p.alpha = 1.0f;
     AF_TRY(DISPATCH(dt, af_launch_conv_gemm<bf16>(p, 1, s), af_launch_conv_gemm<float>(p, 1, s)));
     if (h->ctx_kv[i].xf_pack)   // K and V of this layer as the operand fragments of xattn_fused_kernel
-      AF_TRY(af_launch_xattn_fused_pack(h->ctx_kv[i].kv, 2 * C, (long)n_tokens * 2 * C, n_tokens, Bf, 1.0f / sqrtf((float)x.dh),
+      AF_TRY(af_launch_xattn_fused_pack(h->ctx_kv[i].kv, 2 * C, (long)n_tokens * 2 * C, n_tokens, Bf,
                                         h->ctx_kv[i].xf_pack, s));
     if (h->ctx_kv[i].vt)   // V of this layer as resident fragments (rows of the key list as they now stand)
       AF_TRY(af_launch_attn_short_pack<bf16>(reinterpret_cast<char*>(h->ctx_kv[i].kv) + (size_t)C * 2, 2 * C, (long)n_tokens * 2 * C,

@@ -517,7 +517,7 @@ int af_op_xattn_fused(const float* x_dev, const float* ln_stats_dev, const float
   OP_TRY(af_launch_repack_weight<bf16>(wo_dev, wo, C, C, C, 1, C, 0, 0, s));
   OP_TRY(af_launch_ln_fold<bf16>(wq, wqf, gamma_dev, beta_dev, nullptr, (float*)cs, (float*)bf, rows_pad, C, C, s));
   OP_TRY(af_launch_xattn_fused_permute_wo(wo, C, C, wop, C, s));
-  OP_TRY(af_launch_xattn_fused_pack(kvn, 2 * C, (long)S * 2 * C, S, B, 1.0f / sqrtf((float)dh), pack, s));
+  OP_TRY(af_launch_xattn_fused_pack(kvn, 2 * C, (long)S * 2 * C, S, B, pack, s));
   AfXattnFusedParams a;
   memset(&a, 0, sizeof(a));
   a.x = xn; a.ldx = C; a.M = M; a.rows_per_sample = N;

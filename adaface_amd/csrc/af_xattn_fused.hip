@@ -717,11 +717,11 @@ long af_xattn_fused_pack_elems(int B, int H, int dh, int Nk) {
   if (H != xf::H || dh != xf::DH || Nk <= xf::SMAX - 16 || Nk > xf::SMAX || B <= 0) return 0;
   return (long)B * xf::NPAIR * xf::PACK_ELEMS_PER_PAIR;
 }
-int af_launch_xattn_fused_pack(const void* kv, int ldk, long bsk, int Nk, int B, float scale, void* pack, hipStream_t stream) {
+int af_launch_xattn_fused_pack(const void* kv, int ldk, long bsk, int Nk, int B, void* pack, hipStream_t stream) {
   const long total = (long)B * xf::NPAIR * xf::PACK_ELEMS_PER_PAIR;
   unsigned blocks = (unsigned)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  (void)scale;   // (round 4: K is packed as stored -- no second bf16 rounding; the kernel multiplies the scores by scale * log2 e in fp32)
+  // (round 4: K is packed as stored -- no second bf16 rounding; the kernel multiplies the scores by dh^-1/2 * log2 e in fp32)
   hipLaunchKernelGGL(xf::pack_kv_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const bf16*>(kv), ldk, bsk, Nk, B,
                      reinterpret_cast<bf16*>(pack));
   HIP_CHECK_RET(hipGetLastError());
