@@ -417,6 +417,10 @@ def main():
         parity = {"f32_mode_images_per_sec": B / t32,
                   f"{args.dtype}_final_latent_rel_err": rel, "bar": bar, "within_bar": bool(rel <= bar),
                   f"{args.dtype}_final_latent_max_abs_err": (lat16 - lat32).abs().max().item(), "final_latent_max_abs": sc,
+                  # the rms of the same deviation over the rms of the f32 latent: unlike the max-abs figure it does not move
+                  # with the draw of the rounding noise (DESIGN.md section 2 p')
+                  f"{args.dtype}_final_latent_rms_over_rms": ((lat16 - lat32).double().pow(2).mean().sqrt() /
+                                                              lat32.double().pow(2).mean().sqrt()).item(),
                   "note": "same x_T / context / weights; the f32 (parity) mode is the one pinned to <= 1e-3 max-abs "
                           "against the CPU oracle (tests/test_model_gpu.py::test_config0_*, profiles/*parity_50step*); "
                           f"{args.dtype} is the timed throughput mode and this is its measured deviation after all DDIM steps"}
